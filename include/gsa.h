@@ -1,0 +1,143 @@
+/*
+ * gsa.h -- C ABI of the MI355X-native `generate` hot path
+ * (StyleGAN-v1 synthesis + segmentation decoder -> (image, mask) pairs).
+ *
+ * The reference has no FFI of its own: its boundary is a Python call surface over
+ * MXNet NDArrays.  Each entry point below names the reference
+ * interface it replaces; the ctypes stub a maintainer of the reference would add is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative gsa_status; it never throws and
+ *    never synchronises the stream unless stated;
+ *  - the caller owns every buffer; pointers marked `dev` are device (HBM) pointers valid
+ *    on the context's device, pointers marked `host` are host pointers;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work of a
+ *    call is enqueued on it in order;
+ *  - one context per (device, host thread); contexts are not thread-safe;
+ *  - tensors crossing the boundary use the reference's layouts: fp32 NCHW activations,
+ *    OIHW conv weights, (N,H,W,3) u8 RGB images, (N,H,W) u8 masks.
+ *
+ * The same signatures with the prefix `gsao_` are exported by the CPU oracle
+ * (oracle/c/gsa_oracle.c, test infrastructure only) with every pointer a host pointer.
+ */
+#ifndef GSA_H
+#define GSA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gsa_ctx gsa_ctx;
+
+typedef enum {
+    GSA_OK = 0,
+    GSA_ERR_INVALID = -1,      /* bad argument / shape / unsupported configuration */
+    GSA_ERR_STATE = -2,        /* call order (e.g. forward before commit) */
+    GSA_ERR_MISSING_PARAM = -3,/* a declared parameter was never set (reference: load_parameters without allow_missing) */
+    GSA_ERR_HIP = -4,          /* HIP runtime error; see gsa_last_error */
+    GSA_ERR_NOMEM = -5
+} gsa_status;
+
+/* Generator(config): reference networks_stylegan.py:78-91 (+ image_generator.py:46-74). */
+typedef struct {
+    int32_t max_res_log2;   /* 10 ffhq, 9 cars, 8 bedrooms (reference image_generator.py:11) */
+    int32_t fmap_base;      /* 8192 */
+    double  fmap_decay;     /* 1.0 */
+    int32_t fmap_max;       /* 512 */
+    int32_t latent_size;    /* 512 */
+    int32_t channels;       /* 3 */
+    int32_t use_wscale;     /* 1 */
+} gsa_generator_config;
+
+/* Decoder(cfg): reference networks_seg.py:51-62, seg_solver.py:119-128. */
+typedef struct {
+    int32_t num_feats;            /* len(in_channels) */
+    int32_t start_res;            /* 0 */
+    int32_t use_bn;               /* 1 */
+    const int32_t* features;      /* host, num_feats+1 entries; last = num_classes */
+    const int32_t* in_channels;   /* host, num_feats entries */
+} gsa_decoder_config;
+
+/* Context on HIP device `device`.  Replaces the implicit MXNet context list
+ * (reference image_generator.py:17, seg_solver.py:24-28). */
+int gsa_create(int device, gsa_ctx** out);
+void gsa_destroy(gsa_ctx* ctx);
+
+/* Message of the last failing call on `ctx` (or of the last failing gsa_create when ctx is
+ * NULL).  The reference raises Python exceptions; the Python shim turns this into one. */
+const char* gsa_last_error(const gsa_ctx* ctx);
+
+/* Generator.__init__ (reference networks_stylegan.py:78-112). */
+int gsa_generator_init(gsa_ctx* ctx, const gsa_generator_config* cfg);
+
+/* One tensor of `Generator.load_parameters` (reference image_generator.py:21-22), addressed
+ * by its scheme-P name, fp32, the reference's shape and layout.
+ * Unknown names are ignored (ignore_extra=True) and reported as 1 (not an error). */
+int gsa_generator_set_param(gsa_ctx* ctx, const char* name, const float* host_data,
+                            int32_t ndim, const int64_t* dims);
+
+/* Finish loading: every declared parameter must have been set (no allow_missing in the
+ * reference).  Computes the effective weights (W*std)*lr_mult (reference
+ * networks_stylegan.py:407-412,513-518), repacks them for the kernels and uploads. */
+int gsa_generator_commit(gsa_ctx* ctx);
+
+/* Decoder.__init__ / load_parameters (reference networks_seg.py:51-94, seg_solver.py:339-349);
+ * names are the structural names the reference itself writes. */
+int gsa_decoder_init(gsa_ctx* ctx, const gsa_decoder_config* cfg);
+int gsa_decoder_set_param(gsa_ctx* ctx, const char* name, const float* host_data,
+                          int32_t ndim, const int64_t* dims);
+int gsa_decoder_commit(gsa_ctx* ctx);
+
+/* Size the activation workspace for batches up to `max_batch` samples per call.
+ * (Allocation happens here, never inside a forward call.) */
+int gsa_reserve(gsa_ctx* ctx, int32_t max_batch);
+
+/* Generator.hybrid_forward (reference networks_stylegan.py:165-197) + _transform_gan_back
+ * (reference image_generator.py:76-84).
+ *   z      dev (N, latent_size) fp32
+ *   noise  host array of 2*(max_res_log2-1) dev pointers; plane l is (N,1,R,R) fp32 with
+ *          R = 4,4,8,8,...: the N(0,1) draws of AddNoise (reference networks_stylegan.py:297-300)
+ *   rgb    dev (N,channels,R,R) fp32 or NULL     -- first return value of the reference
+ *   img    dev (N,R,R,channels) u8 or NULL       -- _transform_gan_back of rgb
+ *   feats  NULL or host array of max_res_log2-1 dev pointers, each (N,C_r,R_r,R_r) fp32 or
+ *          NULL                                   -- second return value of the reference */
+int gsa_generator_forward(gsa_ctx* ctx, void* stream, int32_t n, const float* z,
+                          const float* const* noise, float* rgb, uint8_t* img,
+                          float* const* feats);
+
+/* Decoder.hybrid_forward + argmax of SegSolver.predict (reference networks_seg.py:97-113,
+ * seg_solver.py:321-327).
+ *   feats  host array of num_feats dev pointers, each (N,in_channels[i],R_i,R_i) fp32
+ *   logits dev (N,num_classes,R,R) fp32 or NULL
+ *   mask   dev (N,R,R) u8 class index (first maximum wins) or NULL */
+int gsa_decoder_forward(gsa_ctx* ctx, void* stream, int32_t n, const float* const* feats,
+                        float* logits, uint8_t* mask);
+
+/* The fused `main.py generate` step (reference main.py:97-99): generator and decoder with
+ * the feature maps kept in HBM in the kernels' own layout.  Bitwise identical to
+ * gsa_generator_forward + gsa_decoder_forward on the same inputs. */
+int gsa_generate(gsa_ctx* ctx, void* stream, int32_t n, const float* z,
+                 const float* const* noise, uint8_t* img, uint8_t* mask);
+
+/* --- measurement hooks (bench.py) ------------------------------------------------------ */
+
+/* When enabled every kernel launch is bracketed by hipEvents on the launch stream. */
+int gsa_profile_enable(gsa_ctx* ctx, int32_t on);
+/* Synchronises the recorded events and returns the number of distinct kernel labels. */
+int gsa_profile_collect(gsa_ctx* ctx);
+/* Label i: name, accumulated milliseconds, launch count, algorithmic flops and bytes summed
+ * over those launches.  Returns 0, or GSA_ERR_INVALID when i is out of range. */
+int gsa_profile_entry(gsa_ctx* ctx, int32_t i, const char** name, double* ms, int64_t* launches,
+                      double* flops, double* bytes);
+int gsa_profile_reset(gsa_ctx* ctx);
+
+/* Library build string (version, arch). */
+const char* gsa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSA_H */
