@@ -1,0 +1,951 @@
+// Host side of the C ABI (include/gsa.h): context, weight repacking, workspace, and the
+// stream-ordered launch sequences of the generator and the decoder.
+//
+// Reference call sites replaced (reference file:line):
+//   gsa_generator_*  Generator.__init__/load_parameters/hybrid_forward   networks_stylegan.py:78-197,
+//                                                                        image_generator.py:20-22
+//   gsa_decoder_*    Decoder.__init__/load_parameters/hybrid_forward     networks_seg.py:51-113,
+//                                                                        seg_solver.py:307-349
+//   gsa_generate     the per-batch body of `main.py generate`            main.py:97-99
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gsa.h"
+#include "gsa_kernels.h"
+
+using namespace gsa;
+
+namespace {
+
+constexpr int kMaxLevels = 12;
+thread_local std::string g_create_error;
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> dims;
+};
+
+struct GenBlockDev {
+    int C = 0, Cin = 0, R = 0;
+    bool has_conv1 = false, is_deconv = false;
+    float* w1 = nullptr;  // packed conv_1 / deconv_1
+    float* blur = nullptr;
+    float* nscale[2] = {nullptr, nullptr};
+    float* nbias[2] = {nullptr, nullptr};
+    float* w2 = nullptr;
+    float* gamma[2] = {nullptr, nullptr};
+    float* beta[2] = {nullptr, nullptr};
+    int style_off[2] = {0, 0};  // column offset of this layer's 2C styles
+};
+
+struct DecLevelDev {
+    int F = 0, I = 0, in_c = 0, cs = 0;
+    bool is_last = false, has_sc = false;
+    float *cvt_w = nullptr, *cvt_b = nullptr, *cvt_s = nullptr, *cvt_rm = nullptr, *cvt_beta = nullptr;
+    float *a_w = nullptr, *a_b = nullptr, *a_s = nullptr, *a_rm = nullptr, *a_beta = nullptr;
+    float *b_w = nullptr, *b_b = nullptr, *b_s = nullptr, *b_rm = nullptr, *b_beta = nullptr;
+    float *sc_w = nullptr, *sc_b = nullptr;
+    float *f_w = nullptr, *f_b = nullptr;
+};
+
+struct ProfEntry {
+    std::string name;
+    double ms = 0, flops = 0, bytes = 0;
+    int64_t launches = 0;
+};
+
+struct ProfEvent {
+    hipEvent_t a, b;
+    int entry;
+};
+
+}  // namespace
+
+struct gsa_ctx {
+    int device = 0;
+    std::string err;
+    std::vector<void*> g_allocs, d_allocs, ws_allocs;
+
+    // generator
+    bool g_init = false, g_ready = false;
+    gsa_generator_config gc{};
+    std::map<std::string, HostTensor> gparams;
+    int nlev = 0;
+    int ch[kMaxLevels] = {0};
+    float* map_wt[8] = {nullptr};
+    float* map_b[8] = {nullptr};
+    float *latent_avg = nullptr, *psi = nullptr, *constant = nullptr;
+    float *style_wt = nullptr, *style_b = nullptr;
+    int* style_col_layer = nullptr;
+    int style_cols = 0;
+    GenBlockDev blk[kMaxLevels];
+    float *rgb_w = nullptr, *rgb_b = nullptr;
+
+    // decoder
+    bool d_init = false, d_ready = false;
+    int d_n = 0, d_bn = 1;
+    int d_feat[kMaxLevels + 1] = {0}, d_inch[kMaxLevels] = {0};
+    std::map<std::string, HostTensor> dparams;
+    DecLevelDev dl[kMaxLevels];
+
+    // workspace
+    int max_batch = 0;
+    float* lat[2] = {nullptr, nullptr};
+    float* styles = nullptr;
+    float *t_raw = nullptr, *x1 = nullptr;
+    float* x2[kMaxLevels] = {nullptr};
+    Aff* aff1 = nullptr;
+    Aff* aff2[kMaxLevels] = {nullptr};
+    StatPart* partials = nullptr;
+    float* din[kMaxLevels] = {nullptr};
+    float* cvt[kMaxLevels] = {nullptr};
+    float *ya[kMaxLevels] = {nullptr}, *scb[kMaxLevels] = {nullptr}, *prev[kMaxLevels] = {nullptr};
+
+    // profiling
+    int prof = 0;
+    std::vector<ProfEntry> prof_entries;
+    std::vector<ProfEvent> prof_events;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(gsa_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+int hip_fail(gsa_ctx* c, hipError_t e, const char* what) {
+    return fail(c, GSA_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(c, e_, #expr); } while (0)
+
+int nf(const gsa_generator_config& g, int r) {
+    // reference networks_stylegan.py:114-116
+    int fmaps = (int)(g.fmap_base / std::pow(2.0, (r - 1) * g.fmap_decay));
+    return fmaps < g.fmap_max ? fmaps : g.fmap_max;
+}
+
+// (W*std)*lr_mult -- two fp32 roundings, reference networks_stylegan.py:407-412,513-518
+inline float eff(float w, float std, bool use_std, float lr) {
+    float v = use_std ? w * std : w;
+    return v * lr;
+}
+
+int upload(gsa_ctx* c, const std::vector<float>& h, float** out, std::vector<void*>& track) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, h.size() * sizeof(float) + 16));
+    track.push_back(d);
+    HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = (float*)d;
+    return GSA_OK;
+}
+
+template <typename T>
+int dev_alloc(gsa_ctx* c, size_t count, T** out, std::vector<void*>& track) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, count * sizeof(T) + 256));
+    track.push_back(d);
+    *out = (T*)d;
+    return GSA_OK;
+}
+
+void free_all(std::vector<void*>& v) {
+    for (void* p : v) (void)hipFree(p);
+    v.clear();
+}
+
+// conv OIHW (O,I,3,3) -> [g][cb][tap][ci][n][cg]; channel = 16cb+4cg+ci, cout = g*ct+n
+std::vector<float> pack_conv3(const float* w, int O, int I, int ct, float std, bool us, float lr) {
+    std::vector<float> out((size_t)O * I * 9);
+    const int nblk = I / 16, G = O / ct;
+    for (int g = 0; g < G; ++g)
+        for (int cb = 0; cb < nblk; ++cb)
+            for (int t = 0; t < 9; ++t)
+                for (int ci = 0; ci < 4; ++ci)
+                    for (int n = 0; n < ct; ++n)
+                        for (int cg = 0; cg < 4; ++cg) {
+                            const int o = g * ct + n, ch = cb * 16 + cg * 4 + ci;
+                            out[((((((size_t)g * nblk + cb) * 9 + t) * 4 + ci) * ct + n) * 4) + cg] =
+                                eff(w[((size_t)o * I + ch) * 9 + t], std, us, lr);
+                        }
+    return out;
+}
+
+// deconv IOHW (I,O,4,4) -> [g][cb][tap16][ci][n][cg]
+std::vector<float> pack_deconv(const float* w, int I, int O, int ct, float std, bool us, float lr) {
+    std::vector<float> out((size_t)O * I * 16);
+    const int nblk = I / 16, G = O / ct;
+    for (int g = 0; g < G; ++g)
+        for (int cb = 0; cb < nblk; ++cb)
+            for (int t = 0; t < 16; ++t)
+                for (int ci = 0; ci < 4; ++ci)
+                    for (int n = 0; n < ct; ++n)
+                        for (int cg = 0; cg < 4; ++cg) {
+                            const int o = g * ct + n, ch = cb * 16 + cg * 4 + ci;
+                            out[((((((size_t)g * nblk + cb) * 16 + t) * 4 + ci) * ct + n) * 4) + cg] =
+                                eff(w[((size_t)ch * O + o) * 16 + t], std, us, lr);
+                        }
+    return out;
+}
+
+// 1x1 shortcut (O,I,1,1) -> [g][cb][ci][n][cg]
+std::vector<float> pack_conv1(const float* w, int O, int I, int ct) {
+    std::vector<float> out((size_t)O * I);
+    const int nblk = I / 16, G = O / ct;
+    for (int g = 0; g < G; ++g)
+        for (int cb = 0; cb < nblk; ++cb)
+            for (int ci = 0; ci < 4; ++ci)
+                for (int n = 0; n < ct; ++n)
+                    for (int cg = 0; cg < 4; ++cg)
+                        out[(((((size_t)g * nblk + cb) * 4 + ci) * ct + n) * 4) + cg] =
+                            w[(size_t)(g * ct + n) * I + cb * 16 + cg * 4 + ci];
+    return out;
+}
+
+// final conv (K,I,3,3) -> [cb][tap][c16][K]
+std::vector<float> pack_final(const float* w, int K, int I) {
+    std::vector<float> out((size_t)K * I * 9);
+    for (int cb = 0; cb < I / 16; ++cb)
+        for (int t = 0; t < 9; ++t)
+            for (int ci = 0; ci < 16; ++ci)
+                for (int o = 0; o < K; ++o)
+                    out[(((size_t)cb * 9 + t) * 16 + ci) * K + o] = w[((size_t)o * I + cb * 16 + ci) * 9 + t];
+    return out;
+}
+
+const HostTensor* find(const std::map<std::string, HostTensor>& m, const std::string& name) {
+    auto it = m.find(name);
+    return it == m.end() ? nullptr : &it->second;
+}
+
+int need(gsa_ctx* c, const std::map<std::string, HostTensor>& m, const std::string& name, size_t count,
+         const float** out) {
+    const HostTensor* t = find(m, name);
+    if (!t) return fail(c, GSA_ERR_MISSING_PARAM, "parameter %s was not set", name.c_str());
+    if (t->data.size() != count)
+        return fail(c, GSA_ERR_INVALID, "parameter %s has %zu elements, expected %zu", name.c_str(), t->data.size(), count);
+    *out = t->data.data();
+    return GSA_OK;
+}
+
+#define NEED(map, name, count, ptr) do { int rc_ = need(c, map, name, count, ptr); if (rc_) return rc_; } while (0)
+
+int get_std(gsa_ctx* c, const std::string& prefix, float* std) {
+    *std = 1.0f;
+    if (!c->gc.use_wscale) return GSA_OK;
+    const float* p;
+    NEED(c->gparams, prefix + "_std", 1, &p);
+    *std = p[0];
+    return GSA_OK;
+}
+
+bool known_generator_name(const gsa_ctx* c, const char* name) {
+    int R = 0, k = 0, i = 0;
+    char tail[64], t2[64];
+    if (!strcmp(name, "constant_tensor") || !strcmp(name, "latent_avg") || !strcmp(name, "truncation_psi")) return true;
+    if (sscanf(name, "mp_dense_%d_%63s", &i, tail) == 2)
+        return i >= 0 && i < 8 && (!strcmp(tail, "weight") || !strcmp(tail, "bias") || !strcmp(tail, "std"));
+    if (sscanf(name, "%d_%63s", &R, tail) != 2) return false;
+    int r = 0;
+    while ((1 << r) < R) ++r;
+    if ((1 << r) != R || r < 2 || r > c->gc.max_res_log2) return false;
+    if (!strcmp(tail, "conv_1_weight") || !strcmp(tail, "conv_1_std")) return r > 2 && r < 7;
+    if (!strcmp(tail, "deconv_1_weight") || !strcmp(tail, "deconv_1_std")) return r >= 7;
+    if (!strcmp(tail, "blur_1_w_kernel")) return r > 2;
+    if (!strcmp(tail, "conv_2_weight") || !strcmp(tail, "conv_2_std")) return true;
+    if (!strcmp(tail, "conv_to_rgb_weight") || !strcmp(tail, "conv_to_rgb_bias") || !strcmp(tail, "conv_to_rgb_std"))
+        return r == c->gc.max_res_log2;
+    if (sscanf(tail, "noise_%d_%63s", &k, t2) == 2) return (k == 1 || k == 2) && !strcmp(t2, "scale_factors");
+    if (sscanf(tail, "bias_%d_%63s", &k, t2) == 2) return (k == 1 || k == 2) && !strcmp(t2, "bias");
+    if (sscanf(tail, "adain_%d_%63s", &k, t2) == 2)
+        return (k == 1 || k == 2) &&
+               (!strcmp(t2, "dense_affine_weight") || !strcmp(t2, "dense_affine_bias") || !strcmp(t2, "dense_affine_std") ||
+                !strcmp(t2, "norm_gamma") || !strcmp(t2, "norm_beta"));
+    return false;
+}
+
+int set_param(gsa_ctx* c, std::map<std::string, HostTensor>& m, const char* name, const float* data, int ndim,
+              const int64_t* dims) {
+    if (!name || !data || ndim < 0 || ndim > 8) return fail(c, GSA_ERR_INVALID, "bad parameter tensor %s", name ? name : "(null)");
+    HostTensor t;
+    size_t cnt = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (dims[i] < 0) return fail(c, GSA_ERR_INVALID, "negative dimension in %s", name);
+        t.dims.push_back(dims[i]);
+        cnt *= (size_t)dims[i];
+    }
+    t.data.assign(data, data + cnt);
+    m[name] = std::move(t);
+    return GSA_OK;
+}
+
+void reset_generator_dev(gsa_ctx* c) {
+    c->g_ready = false;
+}
+
+// ---------------------------------------------------------------- profiling wrapper
+
+struct Launch {
+    gsa_ctx* c;
+    hipStream_t s;
+    int entry = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    Launch(gsa_ctx* ctx, hipStream_t st, const char* kernel, const char* layer, double flops, double bytes) : c(ctx), s(st) {
+        if (!c->prof) return;
+        std::string key = kernel;
+        if (c->prof > 1 && layer) { key += " | "; key += layer; }
+        for (size_t i = 0; i < c->prof_entries.size(); ++i)
+            if (c->prof_entries[i].name == key) { entry = (int)i; break; }
+        if (entry < 0) {
+            ProfEntry e;
+            e.name = key;
+            c->prof_entries.push_back(e);
+            entry = (int)c->prof_entries.size() - 1;
+        }
+        c->prof_entries[entry].flops += flops;
+        c->prof_entries[entry].bytes += bytes;
+        c->prof_entries[entry].launches += 1;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = get(); b = get();
+        (void)hipEventRecord(a, s);
+    }
+    ~Launch() {
+        if (entry < 0) return;
+        (void)hipEventRecord(b, s);
+        c->prof_events.push_back(ProfEvent{a, b, entry});
+    }
+};
+
+const char* conv_kernel_name(int H, int Cout, int epi, bool sc) {
+    static thread_local char buf[96];
+    const int ct = conv_cout_tile(H, Cout);
+    const int th = H >= 16 ? 16 : H;
+    snprintf(buf, sizeof buf, "conv3x3_mfma<tile%d,cout%d,%s%s>", th, ct,
+             epi == EPI_RAW ? "raw" : (epi == EPI_SYNTH ? "synth" : "dec"), sc ? "+sc" : "");
+    return buf;
+}
+
+}  // namespace
+
+// =========================================================================================
+
+extern "C" {
+
+const char* gsa_version(void) { return "gsa-hip 0.1 (gfx950, v_mfma_f32_16x16x4_f32 implicit-GEMM convs)"; }
+
+int gsa_create(int device, gsa_ctx** out) {
+    if (!out) return fail(nullptr, GSA_ERR_INVALID, "gsa_create: out is null");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, GSA_ERR_HIP, "no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, GSA_ERR_INVALID, "device %d out of range (%d devices)", device, count);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, GSA_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    gsa_ctx* c = new gsa_ctx();
+    c->device = device;
+    *out = c;
+    return GSA_OK;
+}
+
+void gsa_destroy(gsa_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_all(c->g_allocs);
+    free_all(c->d_allocs);
+    free_all(c->ws_allocs);
+    for (auto& ev : c->prof_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+const char* gsa_last_error(const gsa_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+// ------------------------------------------------------------------------ generator setup
+
+int gsa_generator_init(gsa_ctx* c, const gsa_generator_config* g) {
+    if (!c || !g) return GSA_ERR_INVALID;
+    if (g->max_res_log2 < 2 || g->max_res_log2 > kMaxLevels) return fail(c, GSA_ERR_INVALID, "max_res_log2 %d out of range", g->max_res_log2);
+    if (g->latent_size != 512) return fail(c, GSA_ERR_INVALID, "latent_size must be 512 (latent_avg is (512,) in the reference)");
+    if (g->channels < 1 || g->channels > 4) return fail(c, GSA_ERR_INVALID, "channels must be 1..4");
+    c->gc = *g;
+    c->nlev = g->max_res_log2 - 1;
+    for (int l = 0; l < c->nlev; ++l) {
+        c->ch[l] = nf(*g, l + 2);
+        if (c->ch[l] % 16 || c->ch[l] <= 0)
+            return fail(c, GSA_ERR_INVALID, "feature maps at %d px = %d: the MFMA kernels need multiples of 16", 4 << l, c->ch[l]);
+    }
+    c->gparams.clear();
+    c->g_init = true;
+    reset_generator_dev(c);
+    return GSA_OK;
+}
+
+int gsa_generator_set_param(gsa_ctx* c, const char* name, const float* data, int32_t ndim, const int64_t* dims) {
+    if (!c || !c->g_init) return fail(c, GSA_ERR_STATE, "gsa_generator_init first");
+    if (!name) return fail(c, GSA_ERR_INVALID, "null parameter name");
+    if (!known_generator_name(c, name)) return 1;  // ignore_extra=True
+    c->g_ready = false;
+    return set_param(c, c->gparams, name, data, ndim, dims);
+}
+
+int gsa_generator_commit(gsa_ctx* c) {
+    if (!c || !c->g_init) return fail(c, GSA_ERR_STATE, "gsa_generator_init first");
+    HIP_TRY(hipSetDevice(c->device));
+    const auto& P = c->gparams;
+    const int L = c->gc.latent_size;
+    const bool us = c->gc.use_wscale != 0;
+    const float *w, *b;
+    float std;
+    char nm[128];
+    std::vector<float> h;
+    HIP_TRY(hipDeviceSynchronize());
+    c->g_ready = false;
+    free_all(c->g_allocs);
+    auto& T = c->g_allocs;
+
+    const int C0 = c->ch[0];
+    NEED(P, "constant_tensor", (size_t)C0 * 16, &w);
+    h.assign((size_t)C0 * 16, 0.f);
+    for (int ch = 0; ch < C0; ++ch)
+        for (int p = 0; p < 16; ++p) h[(size_t)p * C0 + ch] = w[ch * 16 + p];
+    if (int rc = upload(c, h, &c->constant, T)) return rc;
+    NEED(P, "latent_avg", 512, &w);
+    h.assign(w, w + 512);
+    if (int rc = upload(c, h, &c->latent_avg, T)) return rc;
+    NEED(P, "truncation_psi", (size_t)2 * c->nlev, &w);
+    h.assign(w, w + 2 * c->nlev);
+    if (int rc = upload(c, h, &c->psi, T)) return rc;
+
+    for (int i = 0; i < 8; ++i) {
+        snprintf(nm, sizeof nm, "mp_dense_%d", i);
+        if (int rc = get_std(c, nm, &std)) return rc;
+        NEED(P, std::string(nm) + "_weight", (size_t)L * L, &w);
+        NEED(P, std::string(nm) + "_bias", (size_t)L, &b);
+        h.assign((size_t)L * L, 0.f);
+        for (int j = 0; j < L; ++j)
+            for (int k = 0; k < L; ++k) h[(size_t)k * L + j] = eff(w[(size_t)j * L + k], std, us, 0.01f);  // lr_mult 0.01, reference :135
+        if (int rc = upload(c, h, &c->map_wt[i], T)) return rc;
+        h.assign((size_t)L, 0.f);
+        for (int j = 0; j < L; ++j) h[j] = b[j] * 0.01f;
+        if (int rc = upload(c, h, &c->map_b[i], T)) return rc;
+    }
+
+    // style affines of all 2*nlev layers concatenated on the output axis: WT [L][J], b [J]
+    int J = 0;
+    for (int l = 0; l < c->nlev; ++l) J += 4 * c->ch[l];
+    c->style_cols = J;
+    std::vector<float> swt((size_t)L * J), sb((size_t)J);
+    std::vector<int> col_layer((size_t)J);
+    int col = 0;
+    for (int l = 0; l < c->nlev; ++l) {
+        GenBlockDev& B = c->blk[l];
+        const int r = l + 2, R = 1 << r, C = c->ch[l], Cin = l ? c->ch[l - 1] : C;
+        B.C = C; B.Cin = Cin; B.R = R;
+        B.has_conv1 = r > 2; B.is_deconv = r >= 7;   // reference networks_stylegan.py:154
+        if (B.has_conv1) {
+            snprintf(nm, sizeof nm, "%d_%s", R, B.is_deconv ? "deconv_1" : "conv_1");
+            if (int rc = get_std(c, nm, &std)) return rc;
+            if (B.is_deconv) {
+                NEED(P, std::string(nm) + "_weight", (size_t)Cin * C * 16, &w);
+                h = pack_deconv(w, Cin, C, deconv_cout_tile(C), std, us, 1.0f);
+            } else {
+                NEED(P, std::string(nm) + "_weight", (size_t)Cin * C * 9, &w);
+                h = pack_conv3(w, C, Cin, conv_cout_tile(R, C), std, us, 1.0f);
+            }
+            if (int rc = upload(c, h, &B.w1, T)) return rc;
+            snprintf(nm, sizeof nm, "%d_blur_1_w_kernel", R);
+            NEED(P, nm, (size_t)C * 9, &w);
+            h.assign(w, w + (size_t)C * 9);
+            if (int rc = upload(c, h, &B.blur, T)) return rc;
+        }
+        snprintf(nm, sizeof nm, "%d_conv_2", R);
+        if (int rc = get_std(c, nm, &std)) return rc;
+        NEED(P, std::string(nm) + "_weight", (size_t)C * C * 9, &w);
+        h = pack_conv3(w, C, C, conv_cout_tile(R, C), std, us, 1.0f);
+        if (int rc = upload(c, h, &B.w2, T)) return rc;
+        for (int k = 0; k < 2; ++k) {
+            snprintf(nm, sizeof nm, "%d_noise_%d_scale_factors", R, k + 1);
+            NEED(P, nm, (size_t)C, &w); h.assign(w, w + C);
+            if (int rc = upload(c, h, &B.nscale[k], T)) return rc;
+            snprintf(nm, sizeof nm, "%d_bias_%d_bias", R, k + 1);
+            NEED(P, nm, (size_t)C, &w); h.assign(w, w + C);
+            if (int rc = upload(c, h, &B.nbias[k], T)) return rc;
+            snprintf(nm, sizeof nm, "%d_adain_%d_norm_gamma", R, k + 1);
+            NEED(P, nm, (size_t)C, &w); h.assign(w, w + C);
+            if (int rc = upload(c, h, &B.gamma[k], T)) return rc;
+            snprintf(nm, sizeof nm, "%d_adain_%d_norm_beta", R, k + 1);
+            NEED(P, nm, (size_t)C, &w); h.assign(w, w + C);
+            if (int rc = upload(c, h, &B.beta[k], T)) return rc;
+            snprintf(nm, sizeof nm, "%d_adain_%d_dense_affine", R, k + 1);
+            if (int rc = get_std(c, nm, &std)) return rc;
+            NEED(P, std::string(nm) + "_weight", (size_t)2 * C * L, &w);
+            NEED(P, std::string(nm) + "_bias", (size_t)2 * C, &b);
+            B.style_off[k] = col;
+            for (int j = 0; j < 2 * C; ++j) {
+                for (int q = 0; q < L; ++q) swt[(size_t)q * J + col + j] = eff(w[(size_t)j * L + q], std, us, 1.0f);
+                sb[col + j] = b[j] * 1.0f;
+                col_layer[col + j] = 2 * l + k;
+            }
+            col += 2 * C;
+        }
+    }
+    if (int rc = upload(c, swt, &c->style_wt, T)) return rc;
+    if (int rc = upload(c, sb, &c->style_b, T)) return rc;
+    {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, sizeof(int) * J));
+        T.push_back(d);
+        HIP_TRY(hipMemcpy(d, col_layer.data(), sizeof(int) * J, hipMemcpyHostToDevice));
+        c->style_col_layer = (int*)d;
+    }
+    {
+        const int R = 1 << c->gc.max_res_log2, C = c->ch[c->nlev - 1], nc = c->gc.channels;
+        snprintf(nm, sizeof nm, "%d_conv_to_rgb", R);
+        if (int rc = get_std(c, nm, &std)) return rc;
+        NEED(P, std::string(nm) + "_weight", (size_t)nc * C, &w);
+        NEED(P, std::string(nm) + "_bias", (size_t)nc, &b);
+        h.assign((size_t)nc * C, 0.f);
+        for (size_t i = 0; i < (size_t)nc * C; ++i) h[i] = eff(w[i], std, us, 1.0f);
+        if (int rc = upload(c, h, &c->rgb_w, T)) return rc;
+        h.assign(b, b + nc);
+        if (int rc = upload(c, h, &c->rgb_b, T)) return rc;
+    }
+    c->g_ready = true;
+    return GSA_OK;
+}
+
+// ------------------------------------------------------------------------ decoder setup
+
+int gsa_decoder_init(gsa_ctx* c, const gsa_decoder_config* d) {
+    if (!c || !d || !d->features || !d->in_channels) return GSA_ERR_INVALID;
+    if (d->num_feats < 1 || d->num_feats > kMaxLevels) return fail(c, GSA_ERR_INVALID, "num_feats %d out of range", d->num_feats);
+    if (d->start_res != 0) return fail(c, GSA_ERR_INVALID, "start_res != 0 is not supported");
+    c->d_n = d->num_feats;
+    c->d_bn = d->use_bn;
+    for (int i = 0; i <= d->num_feats; ++i) c->d_feat[i] = d->features[i];
+    for (int i = 0; i < d->num_feats; ++i) {
+        c->d_inch[i] = d->in_channels[i];
+        if (c->d_inch[i] % 16 || c->d_feat[i] % 16 || c->d_inch[i] <= 0 || c->d_feat[i] <= 0)
+            return fail(c, GSA_ERR_INVALID, "decoder level %d: channel counts must be positive multiples of 16", i);
+    }
+    const int ncls = c->d_feat[d->num_feats];
+    if (ncls < 1 || ncls > 8) return fail(c, GSA_ERR_INVALID, "num_classes %d not in 1..8", ncls);
+    if (d->num_feats < 3) return fail(c, GSA_ERR_INVALID, "the final resolution must be at least 16 px (num_feats >= 3)");
+    c->dparams.clear();
+    c->d_init = true;
+    c->d_ready = false;
+    return GSA_OK;
+}
+
+int gsa_decoder_set_param(gsa_ctx* c, const char* name, const float* data, int32_t ndim, const int64_t* dims) {
+    if (!c || !c->d_init) return fail(c, GSA_ERR_STATE, "gsa_decoder_init first");
+    c->d_ready = false;
+    return set_param(c, c->dparams, name, data, ndim, dims);
+}
+
+static int load_bn(gsa_ctx* c, const std::string& prefix, int C, float** s, float** rm, float** beta) {
+    std::vector<float> hs((size_t)C, 1.0f), hm((size_t)C, 0.0f), hb((size_t)C, 0.0f);
+    if (c->d_bn) {
+        const float *g, *b, *m, *v;
+        NEED(c->dparams, prefix + ".gamma", (size_t)C, &g);
+        NEED(c->dparams, prefix + ".beta", (size_t)C, &b);
+        NEED(c->dparams, prefix + ".running_mean", (size_t)C, &m);
+        NEED(c->dparams, prefix + ".running_var", (size_t)C, &v);
+        for (int i = 0; i < C; ++i) {
+            hs[i] = g[i] / std::sqrt(v[i] + 1e-5f);   // fp32: sqrtf, then one division
+            hm[i] = m[i];
+            hb[i] = b[i];
+        }
+    }
+    if (int rc = upload(c, hs, s, c->d_allocs)) return rc;
+    if (int rc = upload(c, hm, rm, c->d_allocs)) return rc;
+    return upload(c, hb, beta, c->d_allocs);
+}
+
+int gsa_decoder_commit(gsa_ctx* c) {
+    if (!c || !c->d_init) return fail(c, GSA_ERR_STATE, "gsa_decoder_init first");
+    HIP_TRY(hipSetDevice(c->device));
+    const auto& P = c->dparams;
+    const int n = c->d_n;
+    char nm[160];
+    const float *w, *b;
+    std::vector<float> h;
+    HIP_TRY(hipDeviceSynchronize());
+    c->d_ready = false;
+    free_all(c->d_allocs);
+    auto& T = c->d_allocs;
+    for (int i = 0; i < n; ++i) {
+        DecLevelDev& d = c->dl[i];
+        const int R = 4 << i;
+        d.F = c->d_feat[i]; d.I = c->d_inch[i];
+        d.cs = c->d_feat[i + 1];
+        d.in_c = d.F * (i > 0 ? 2 : 1);
+        d.is_last = i == n - 1;
+        snprintf(nm, sizeof nm, "cvt_block_%d.0", i);
+        NEED(P, std::string(nm) + ".weight", (size_t)d.F * d.I * 9, &w);
+        NEED(P, std::string(nm) + ".bias", (size_t)d.F, &b);
+        h = pack_conv3(w, d.F, d.I, conv_cout_tile(R, d.F), 1.0f, false, 1.0f);
+        if (int rc = upload(c, h, &d.cvt_w, T)) return rc;
+        h.assign(b, b + d.F);
+        if (int rc = upload(c, h, &d.cvt_b, T)) return rc;
+        snprintf(nm, sizeof nm, "cvt_block_%d.1", i);
+        if (int rc = load_bn(c, nm, d.F, &d.cvt_s, &d.cvt_rm, &d.cvt_beta)) return rc;
+        if (!d.is_last) {
+            const int second = c->d_bn ? 3 : 2, R2 = 2 * R;
+            const std::string pf = "main_block_" + std::to_string(i) + ".1.base_layers";
+            NEED(P, pf + ".0.weight", (size_t)d.cs * d.in_c * 9, &w);
+            NEED(P, pf + ".0.bias", (size_t)d.cs, &b);
+            h = pack_conv3(w, d.cs, d.in_c, conv_cout_tile(R2, d.cs), 1.0f, false, 1.0f);
+            if (int rc = upload(c, h, &d.a_w, T)) return rc;
+            h.assign(b, b + d.cs);
+            if (int rc = upload(c, h, &d.a_b, T)) return rc;
+            if (int rc = load_bn(c, pf + ".1", d.cs, &d.a_s, &d.a_rm, &d.a_beta)) return rc;
+            NEED(P, pf + "." + std::to_string(second) + ".weight", (size_t)d.cs * d.cs * 9, &w);
+            NEED(P, pf + "." + std::to_string(second) + ".bias", (size_t)d.cs, &b);
+            h = pack_conv3(w, d.cs, d.cs, conv_cout_tile(R2, d.cs), 1.0f, false, 1.0f);
+            if (int rc = upload(c, h, &d.b_w, T)) return rc;
+            h.assign(b, b + d.cs);
+            if (int rc = upload(c, h, &d.b_b, T)) return rc;
+            if (int rc = load_bn(c, pf + "." + std::to_string(second + 1), d.cs, &d.b_s, &d.b_rm, &d.b_beta)) return rc;
+            d.has_sc = d.cs != d.in_c;
+            if (d.has_sc) {
+                const std::string sc = "main_block_" + std::to_string(i) + ".1.shortcut.0";
+                NEED(P, sc + ".weight", (size_t)d.cs * d.in_c, &w);
+                NEED(P, sc + ".bias", (size_t)d.cs, &b);
+                h = pack_conv1(w, d.cs, d.in_c, conv_cout_tile(R2, d.cs));
+                if (int rc = upload(c, h, &d.sc_w, T)) return rc;
+                h.assign(b, b + d.cs);
+                if (int rc = upload(c, h, &d.sc_b, T)) return rc;
+            } else if (i > 0) {
+                return fail(c, GSA_ERR_INVALID, "decoder level %d: identity shortcut over a concatenated input is not supported", i);
+            }
+        } else {
+            const std::string pf = "main_block_" + std::to_string(i) + ".0";
+            NEED(P, pf + ".weight", (size_t)d.cs * d.in_c * 9, &w);
+            NEED(P, pf + ".bias", (size_t)d.cs, &b);
+            h = pack_final(w, d.cs, d.in_c);
+            if (int rc = upload(c, h, &d.f_w, T)) return rc;
+            h.assign(b, b + d.cs);
+            if (int rc = upload(c, h, &d.f_b, T)) return rc;
+        }
+    }
+    c->d_ready = true;
+    return GSA_OK;
+}
+
+// ------------------------------------------------------------------------ workspace
+
+int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
+    if (!c) return GSA_ERR_INVALID;
+    if (max_batch < 1) return fail(c, GSA_ERR_INVALID, "max_batch must be >= 1");
+    if (!c->g_ready && !c->d_ready) return fail(c, GSA_ERR_STATE, "commit a generator or decoder before gsa_reserve");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    free_all(c->ws_allocs);
+    c->max_batch = 0;
+    const size_t N = (size_t)max_batch;
+    auto& T = c->ws_allocs;
+    size_t prow_elems = 0;   // max over layers of rows*C
+    if (c->g_ready) {
+        const int L = c->gc.latent_size;
+        for (int i = 0; i < 2; ++i)
+            if (int rc = dev_alloc(c, N * L, &c->lat[i], T)) return rc;
+        if (int rc = dev_alloc(c, N * c->style_cols, &c->styles, T)) return rc;
+        size_t maxact = 0;
+        int maxC = 0;
+        for (int l = 0; l < c->nlev; ++l) {
+            const size_t R = (size_t)4 << l, C = (size_t)c->ch[l];
+            maxact = std::max(maxact, R * R * C);
+            maxC = std::max(maxC, c->ch[l]);
+            if (int rc = dev_alloc(c, N * R * R * C, &c->x2[l], T)) return rc;
+            if (int rc = dev_alloc(c, N * C, &c->aff2[l], T)) return rc;
+            prow_elems = std::max(prow_elems, (size_t)conv_stat_rows((int)R, (int)R, (int)C) * C);
+            prow_elems = std::max(prow_elems, (size_t)post_prow((int)R, (int)R, (int)C) * C);
+        }
+        if (int rc = dev_alloc(c, N * maxact, &c->t_raw, T)) return rc;
+        if (int rc = dev_alloc(c, N * maxact, &c->x1, T)) return rc;
+        if (int rc = dev_alloc(c, N * maxC, &c->aff1, T)) return rc;
+        if (int rc = dev_alloc(c, N * prow_elems, &c->partials, T)) return rc;
+    }
+    if (c->d_ready) {
+        for (int i = 0; i < c->d_n; ++i) {
+            const DecLevelDev& d = c->dl[i];
+            const size_t R = (size_t)4 << i;
+            if (int rc = dev_alloc(c, N * R * R * d.I, &c->din[i], T)) return rc;
+            if (int rc = dev_alloc(c, N * R * R * d.F, &c->cvt[i], T)) return rc;
+            if (!d.is_last) {
+                if (int rc = dev_alloc(c, N * 4 * R * R * d.cs, &c->ya[i], T)) return rc;
+                if (int rc = dev_alloc(c, N * 4 * R * R * d.cs, &c->prev[i], T)) return rc;
+                if (d.has_sc)
+                    if (int rc = dev_alloc(c, N * 4 * R * R * d.cs, &c->scb[i], T)) return rc;
+            }
+        }
+    }
+    c->max_batch = max_batch;
+    return GSA_OK;
+}
+
+// ------------------------------------------------------------------------ forward passes
+
+static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const float* const* noise, float* rgb,
+                         uint8_t* img, float* const* feats) {
+    const int L = c->gc.latent_size, nlev = c->nlev;
+    const double N = n;
+    // mapping network: PixelNorm, 8 x (dense + LeakyReLU)
+    { Launch lp(c, s, "pixelnorm_kernel", "g.mapping.pixelnorm", 3.0 * N * L, 8.0 * N * L);
+      HIP_TRY(launch_pixelnorm(z, c->lat[0], n, L, s)); }
+    int cur = 0;
+    for (int i = 0; i < 8; ++i) {
+        Launch lp(c, s, "dense_kernel", "g.mapping.dense", 2.0 * N * L * L, 4.0 * (L * (double)L + 2 * N * L));
+        HIP_TRY(launch_dense(c->lat[cur], c->map_wt[i], c->map_b[i], c->lat[cur ^ 1], n, L, L, 1, s));
+        cur ^= 1;
+    }
+    const float* w = c->lat[cur];
+    { Launch lp(c, s, "styles_kernel", "g.styles", 2.0 * N * L * c->style_cols, 4.0 * ((double)L * c->style_cols + N * c->style_cols));
+      HIP_TRY(launch_styles(w, c->latent_avg, c->psi, c->style_wt, c->style_b, c->style_col_layer, c->styles, n, L, c->style_cols, s)); }
+
+    char layer[64];
+    for (int l = 0; l < nlev; ++l) {
+        const GenBlockDev& B = c->blk[l];
+        const int R = B.R, C = B.C, Cin = B.Cin;
+        const double px = N * R * R;
+        for (int k = 0; k < 2; ++k) {
+            const float* nz = noise[2 * l + k];
+            if (!nz) return fail(c, GSA_ERR_INVALID, "noise plane %d is null", 2 * l + k);
+            int prow = 0;
+            if (k == 0) {
+                PostParams pp{};
+                pp.noise = nz; pp.nscale = B.nscale[0]; pp.nbias = B.nbias[0];
+                pp.out = c->x1; pp.partials = c->partials; pp.H = R; pp.W = R; pp.C = C;
+                if (!B.has_conv1) {
+                    pp.src = c->constant; pp.src_per_sample = 0; pp.blur = nullptr;
+                } else {
+                    ConvParams cp{};
+                    cp.src0 = c->x2[l - 1]; cp.aff0 = c->aff2[l - 1]; cp.C0 = Cin;
+                    cp.Hs = R / 2; cp.Ws = R / 2; cp.H = R; cp.W = R;
+                    cp.wpk = B.w1; cp.Cout = C; cp.out = c->t_raw;
+                    if (B.is_deconv) {
+                        snprintf(layer, sizeof layer, "g.%d.deconv_1", R);
+                        static thread_local char kn[64];
+                        snprintf(kn, sizeof kn, "deconv4x4_mfma<cout%d>", deconv_cout_tile(C));
+                        Launch lp(c, s, kn, layer, 2.0 * px * C * Cin * 4, 4.0 * (px / 4 * Cin + px * C));
+                        HIP_TRY(launch_deconv4x4(cp, n, s));
+                    } else {
+                        cp.up = 1;
+                        snprintf(layer, sizeof layer, "g.%d.conv_1", R);
+                        Launch lp(c, s, conv_kernel_name(R, C, EPI_RAW, false), layer, 2.0 * px * C * Cin * 9, 4.0 * (px / 4 * Cin + px * C));
+                        HIP_TRY(launch_conv3x3(cp, EPI_RAW, false, n, s));
+                    }
+                    pp.src = c->t_raw; pp.src_per_sample = 1; pp.blur = B.blur;
+                }
+                snprintf(layer, sizeof layer, "g.%d.post_1", R);
+                Launch lp(c, s, pp.blur ? "post_kernel<blur>" : "post_kernel<const>", layer, 0.0, 4.0 * (2 * px * C + px));
+                HIP_TRY(launch_post(pp, n, s));
+                prow = post_prow(R, R, C);
+            } else {
+                ConvParams cp{};
+                cp.src0 = c->x1; cp.aff0 = c->aff1; cp.C0 = C;
+                cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
+                cp.wpk = B.w2; cp.Cout = C; cp.out = c->x2[l];
+                cp.noise = nz; cp.nscale = B.nscale[1]; cp.nbias = B.nbias[1]; cp.partials = c->partials;
+                snprintf(layer, sizeof layer, "g.%d.conv_2", R);
+                Launch lp(c, s, conv_kernel_name(R, C, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
+                HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
+                prow = conv_stat_rows(R, R, C);
+            }
+            FinalizeParams fp{};
+            fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C;
+            fp.style = c->styles + B.style_off[k]; fp.style_stride = c->style_cols;
+            fp.gamma = B.gamma[k]; fp.beta = B.beta[k];
+            fp.aff = k == 0 ? c->aff1 : c->aff2[l];
+            snprintf(layer, sizeof layer, "g.%d.finalize_%d", R, k + 1);
+            Launch lp(c, s, "finalize_kernel", layer, 0.0, 16.0 * N * prow * C);
+            HIP_TRY(launch_finalize(fp, n, s));
+        }
+        if (feats && feats[l]) {
+            snprintf(layer, sizeof layer, "g.%d.export", R);
+            Launch lp(c, s, "export_nchw_kernel", layer, 0.0, 8.0 * px * C);
+            HIP_TRY(launch_export_nchw(c->x2[l], c->aff2[l], feats[l], n, R, R, C, s));
+        }
+    }
+    if (rgb || img) {
+        const int l = nlev - 1, R = c->blk[l].R, C = c->blk[l].C, nc = c->gc.channels;
+        const double px = N * R * R;
+        Launch lp(c, s, "torgb_kernel", "g.torgb", 2.0 * px * C * nc, px * (4.0 * C + (rgb ? 4.0 * nc : 0) + (img ? nc : 0)));
+        HIP_TRY(launch_torgb(c->x2[l], c->aff2[l], c->rgb_w, c->rgb_b, rgb, img, n, R, R, C, nc, s));
+    }
+    return GSA_OK;
+}
+
+// feats_nhwc[i] / feat_aff[i]: decoder inputs in kernel layout (aff may be null)
+static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsrc, const Aff* const* faff, float* logits,
+                       uint8_t* mask) {
+    const int nl = c->d_n;
+    const double N = n;
+    char layer[64];
+    for (int i = 0; i < nl; ++i) {
+        const DecLevelDev& d = c->dl[i];
+        const int R = 4 << i;
+        const double px = N * R * R;
+        {   // cvt_block: conv3x3+bias -> BN -> LeakyReLU (Dropout is identity at inference)
+            ConvParams cp{};
+            cp.src0 = fsrc[i]; cp.aff0 = faff ? faff[i] : nullptr; cp.C0 = d.I;
+            cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
+            cp.wpk = d.cvt_w; cp.Cout = d.F; cp.out = c->cvt[i];
+            cp.bias = d.cvt_b; cp.bn_s = d.cvt_s; cp.bn_rm = d.cvt_rm; cp.bn_beta = d.cvt_beta;
+            snprintf(layer, sizeof layer, "d.cvt_%d", i);
+            Launch lp(c, s, conv_kernel_name(R, d.F, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
+            HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
+        }
+        if (!d.is_last) {
+            const int R2 = 2 * R;
+            const double px2 = 4 * px;
+            {   // ResBlock conv a (+ fused 1x1 shortcut) on nearest-x2(concat(prev, cvt))
+                ConvParams cp{};
+                if (i > 0) { cp.src0 = c->prev[i - 1]; cp.C0 = d.F; cp.src1 = c->cvt[i]; cp.C1 = d.F; }
+                else { cp.src0 = c->cvt[i]; cp.C0 = d.F; }
+                cp.Hs = R; cp.Ws = R; cp.up = 1; cp.H = R2; cp.W = R2;
+                cp.wpk = d.a_w; cp.Cout = d.cs; cp.out = c->ya[i];
+                cp.bias = d.a_b; cp.bn_s = d.a_s; cp.bn_rm = d.a_rm; cp.bn_beta = d.a_beta;
+                if (d.has_sc) { cp.wsc = d.sc_w; cp.sc_bias = d.sc_b; cp.out_sc = c->scb[i]; }
+                snprintf(layer, sizeof layer, "d.main_%d.a", i);
+                Launch lp(c, s, conv_kernel_name(R2, d.cs, EPI_DEC, d.has_sc), layer,
+                          2.0 * px2 * d.cs * d.in_c * (9 + (d.has_sc ? 1 : 0)), 4.0 * (px * d.in_c + px2 * d.cs * (d.has_sc ? 2 : 1)));
+                HIP_TRY(launch_conv3x3(cp, EPI_DEC, d.has_sc, n, s));
+            }
+            {   // ResBlock conv b, + shortcut
+                ConvParams cp{};
+                cp.src0 = c->ya[i]; cp.C0 = d.cs;
+                cp.Hs = R2; cp.Ws = R2; cp.H = R2; cp.W = R2;
+                cp.wpk = d.b_w; cp.Cout = d.cs; cp.out = c->prev[i];
+                cp.bias = d.b_b; cp.bn_s = d.b_s; cp.bn_rm = d.b_rm; cp.bn_beta = d.b_beta;
+                if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = 0; }
+                else { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
+                snprintf(layer, sizeof layer, "d.main_%d.b", i);
+                Launch lp(c, s, conv_kernel_name(R2, d.cs, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
+                HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
+            }
+        } else {
+            snprintf(layer, sizeof layer, "d.final_%d", i);
+            Launch lp(c, s, "final_conv_kernel", layer, 2.0 * px * d.cs * d.in_c * 9, px * (4.0 * d.in_c + (logits ? 4.0 * d.cs : 0) + (mask ? 1 : 0)));
+            HIP_TRY(launch_final_conv(c->prev[i - 1], d.F, c->cvt[i], d.F, d.f_w, d.f_b, logits, mask, n, R, R, d.cs, s));
+        }
+    }
+    return GSA_OK;
+}
+
+static int check_batch(gsa_ctx* c, int n) {
+    if (n < 1) return fail(c, GSA_ERR_INVALID, "batch size %d < 1", n);
+    if (n > c->max_batch) return fail(c, GSA_ERR_STATE, "batch %d exceeds the reserved workspace (%d): call gsa_reserve", n, c->max_batch);
+    return GSA_OK;
+}
+
+int gsa_generator_forward(gsa_ctx* c, void* stream, int32_t n, const float* z, const float* const* noise, float* rgb,
+                          uint8_t* img, float* const* feats) {
+    if (!c) return GSA_ERR_INVALID;
+    if (!c->g_ready) return fail(c, GSA_ERR_STATE, "gsa_generator_commit first");
+    if (!z || !noise) return fail(c, GSA_ERR_INVALID, "z and noise must not be null");
+    if (int rc = check_batch(c, n)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    return run_generator(c, (hipStream_t)stream, n, z, noise, rgb, img, feats);
+}
+
+int gsa_decoder_forward(gsa_ctx* c, void* stream, int32_t n, const float* const* feats, float* logits, uint8_t* mask) {
+    if (!c) return GSA_ERR_INVALID;
+    if (!c->d_ready) return fail(c, GSA_ERR_STATE, "gsa_decoder_commit first");
+    if (!feats) return fail(c, GSA_ERR_INVALID, "feats must not be null");
+    if (int rc = check_batch(c, n)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const float* fsrc[kMaxLevels];
+    for (int i = 0; i < c->d_n; ++i) {
+        if (!feats[i]) return fail(c, GSA_ERR_INVALID, "feature %d is null", i);
+        const int R = 4 << i;
+        Launch lp(c, s, "import_nhwc_kernel", "d.import", 0.0, 8.0 * n * R * R * c->dl[i].I);
+        HIP_TRY(launch_import_nhwc(feats[i], c->din[i], n, R, R, c->dl[i].I, s));
+        fsrc[i] = c->din[i];
+    }
+    return run_decoder(c, s, n, fsrc, nullptr, logits, mask);
+}
+
+int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const float* const* noise, uint8_t* img, uint8_t* mask) {
+    if (!c) return GSA_ERR_INVALID;
+    if (!c->g_ready || !c->d_ready) return fail(c, GSA_ERR_STATE, "commit both generator and decoder first");
+    if (!z || !noise) return fail(c, GSA_ERR_INVALID, "z and noise must not be null");
+    if (c->d_n != c->nlev) return fail(c, GSA_ERR_INVALID, "decoder expects %d features, the generator yields %d", c->d_n, c->nlev);
+    for (int l = 0; l < c->nlev; ++l)
+        if (c->d_inch[l] != c->ch[l]) return fail(c, GSA_ERR_INVALID, "decoder in_channels[%d]=%d but the generator feature has %d", l, c->d_inch[l], c->ch[l]);
+    if (int rc = check_batch(c, n)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = run_generator(c, s, n, z, noise, nullptr, img, nullptr)) return rc;
+    const float* fsrc[kMaxLevels];
+    const Aff* faff[kMaxLevels];
+    for (int l = 0; l < c->nlev; ++l) { fsrc[l] = c->x2[l]; faff[l] = c->aff2[l]; }
+    return run_decoder(c, s, n, fsrc, faff, nullptr, mask);
+}
+
+// ------------------------------------------------------------------------ measurement hooks
+
+int gsa_profile_enable(gsa_ctx* c, int32_t on) {
+    if (!c) return GSA_ERR_INVALID;
+    c->prof = on;
+    return GSA_OK;
+}
+
+int gsa_profile_collect(gsa_ctx* c) {
+    if (!c) return GSA_ERR_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    for (auto& ev : c->prof_events) {
+        HIP_TRY(hipEventSynchronize(ev.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+        c->prof_entries[ev.entry].ms += ms;
+        c->event_pool.push_back(ev.a);
+        c->event_pool.push_back(ev.b);
+    }
+    c->prof_events.clear();
+    return (int)c->prof_entries.size();
+}
+
+int gsa_profile_entry(gsa_ctx* c, int32_t i, const char** name, double* ms, int64_t* launches, double* flops, double* bytes) {
+    if (!c || i < 0 || i >= (int)c->prof_entries.size()) return GSA_ERR_INVALID;
+    const ProfEntry& e = c->prof_entries[i];
+    if (name) *name = e.name.c_str();
+    if (ms) *ms = e.ms;
+    if (launches) *launches = e.launches;
+    if (flops) *flops = e.flops;
+    if (bytes) *bytes = e.bytes;
+    return GSA_OK;
+}
+
+int gsa_profile_reset(gsa_ctx* c) {
+    if (!c) return GSA_ERR_INVALID;
+    int rc = gsa_profile_collect(c);
+    if (rc < 0) return rc;
+    c->prof_entries.clear();
+    return GSA_OK;
+}
+
+}  // extern "C"

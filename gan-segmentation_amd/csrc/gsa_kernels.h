@@ -1,0 +1,82 @@
+// Kernel launch interface between the host orchestration (gsa_api.cpp) and the HIP kernels
+// (gsa_kernels.hip).  Internal; the public boundary is include/gsa.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsa {
+
+// Per-(sample, channel) AdaIN coefficients: out = fmaf(x - mean, A, B)
+// (InstanceNorm + style of reference networks_stylegan.py:250-264, folded).
+struct Aff { float mean, A, B, pad; };
+
+// 64-bit fixed-point partial statistics of one (sample, tile-row, channel)
+struct StatPart { unsigned long long s1, s2; };
+
+constexpr double kStatScale1 = 268435456.0;  // 2^28: quad sums
+constexpr double kStatScale2 = 1048576.0;    // 2^20: quad sums of squares
+
+enum Epilogue { EPI_RAW = 0, EPI_SYNTH = 1, EPI_DEC = 2 };
+
+struct ConvParams {
+    // input: up to two NHWC sources concatenated on channels (C0 then C1), both multiples of 16
+    const float* src0; const Aff* aff0; int C0;   // aff0 may be null (identity)
+    const float* src1; int C1;                    // src1 may be null
+    int Hs, Ws;      // spatial size of the sources
+    int up;          // 1: logical input is the nearest x2 upsample of the sources
+    int H, W;        // output size
+    const float* wpk;   // packed weights [cout group][c16][tap][ci][n][cg]
+    int Cout;           // total output channels
+    float* out;         // NHWC
+    // EPI_SYNTH: AddNoise -> Bias -> LeakyReLU -> statistics
+    const float* noise; const float* nscale; const float* nbias;
+    StatPart* partials; int prow;      // prow = partial rows per sample
+    // EPI_DEC: conv bias -> BatchNorm(inference) -> LeakyReLU [-> + resid]
+    const float* bias; const float* bn_s; const float* bn_rm; const float* bn_beta;
+    const float* resid; int resid_up;   // resid_up: residual lives at half resolution (identity shortcut)
+    // fused 1x1 shortcut of DecoderResBlock (second output)
+    const float* wsc; const float* sc_bias; float* out_sc;
+    int tiles_x;
+};
+
+struct PostParams {
+    const float* src;      // raw conv_1 output NHWC, or the constant tensor [H][W][C]
+    int src_per_sample;    // 1: src indexed by sample; 0: broadcast (constant tensor)
+    const float* blur;     // [C][9] or null (no blur)
+    const float* noise; const float* nscale; const float* nbias;
+    float* out; StatPart* partials; int prow;
+    int H, W, C;
+};
+
+struct FinalizeParams {
+    const StatPart* partials; int prow; int HW; int C;
+    const float* style; int style_stride;  // style[n*style_stride + c] = ys, [.. + C + c] = yb
+    const float* gamma; const float* beta;
+    Aff* aff;   // [n][C]
+};
+
+// launches (all stream-ordered, no sync)
+hipError_t launch_conv3x3(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);
+hipError_t launch_deconv4x4(const ConvParams& p, int n, hipStream_t s);
+hipError_t launch_post(const PostParams& p, int n, hipStream_t s);
+hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);
+hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_t s);
+hipError_t launch_dense(const float* x, const float* WT, const float* b, float* y, int n, int K, int J,
+                        int lrelu, hipStream_t s);
+hipError_t launch_styles(const float* w, const float* avg, const float* psi, const float* WT, const float* b,
+                         const int* col_layer, float* styles, int n, int K, int J, hipStream_t s);
+hipError_t launch_torgb(const float* x, const Aff* aff, const float* w, const float* b, float* rgb,
+                        uint8_t* img, int n, int H, int W, int C, int nc, hipStream_t s);
+hipError_t launch_export_nchw(const float* x, const Aff* aff, float* out, int n, int H, int W, int C, hipStream_t s);
+hipError_t launch_import_nhwc(const float* in, float* out, int n, int H, int W, int C, hipStream_t s);
+hipError_t launch_final_conv(const float* src0, int C0, const float* src1, int C1, const float* wpk,
+                             const float* bias, float* logits, uint8_t* mask, int n, int H, int W, int ncls,
+                             hipStream_t s);
+
+// packing geometry shared with the host-side weight packer
+int conv_cout_tile(int H, int Cout);          // output channels per workgroup of conv3x3 at output size H
+int deconv_cout_tile(int Cout);               // ... of deconv4x4
+int conv_stat_rows(int H, int W, int Cout);   // statistic partial rows per sample written by conv3x3 EPI_SYNTH
+int post_prow(int H, int W, int C);           // ... written by the post kernel
+
+}  // namespace gsa

@@ -1,0 +1,856 @@
+// HIP kernels of the `generate` hot path for gfx950 (MI355X, CDNA4).
+//
+// Layout: activations are NHWC fp32 in HBM.  Instance-norm + style (AdaIN) is never
+// materialised: a producer stores its post-LeakyReLU tensor plus fixed-point statistics,
+// a tiny finalize kernel turns them into per-(sample,channel) coefficients (mean, A, B) and
+// every consumer applies fmaf(x - mean, A, B) while staging its input tile into LDS.
+//
+// All convolutions are implicit GEMMs on the exact-fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32): M = a 4x4 patch of output pixels, N = 16 output channels,
+// K = 4 input channels per instruction.  The MFMA is bitwise a k-ordered fmaf chain, so with
+// the K order fixed to (16-channel block, tap, channel) the kernels reproduce the canonical
+// arithmetic of oracle/c/gsa_oracle.c bit for bit (DESIGN.md "Canonical arithmetic").
+//
+// Reference operators replaced (reference file:line):
+//   conv3x3_mfma    Conv2DW 3x3 (+UpSample nearest)   networks_stylegan.py:354-457, 308-315
+//                   nn.Conv2D+BatchNorm+LeakyReLU       networks_seg.py:14-46, 68-76
+//   deconv4x4_mfma  Conv2DTransposeW k4 s2 p1           networks_stylegan.py:460-476
+//   post_kernel     Blur, AddNoise, Bias, LeakyReLU     networks_stylegan.py:200-236, 267-305, 534-545
+//   finalize_kernel InstanceNorm + AdaIN style          networks_stylegan.py:239-264
+//   dense / styles  PixelNorm, DenseW, lerp             networks_stylegan.py:128-139, 158-163, 479-524, 558-565
+//   torgb_kernel    toRGB + _transform_gan_back         networks_stylegan.py:118-126; image_generator.py:76-84
+//   final_conv      final Conv2D + argmax               networks_seg.py:91-92; seg_solver.py:326
+#include "gsa_kernels.h"
+
+namespace gsa {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.0f ? v : 0.2f * v; }
+
+// rint(v * scale) as a wrapping 64-bit integer (1.5*2^52 magic constant); order-independent sums
+__device__ __forceinline__ unsigned long long to_fixed(float v, double scale) {
+    const double magic = 6755399441055744.0;
+    double t = fma((double)v, scale, magic);
+    return (unsigned long long)__double_as_longlong(t) - (unsigned long long)__double_as_longlong(magic);
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// conv3x3 (pad 1) as implicit GEMM on v_mfma_f32_16x16x4_f32.
+//
+// Workgroup = WM*WN waves, output tile TH x TW pixels x COUT_T = 16*NT*WN channels.
+// LDS image of the input tile (with 1-pixel halo): [row][pixel][16 channels], the 16 channels
+// of a block stored transposed 4x4 (position ci*4+cg holds channel 4*cg+ci) so that one
+// ds_read_b128 per lane yields the A operands of 4 consecutive MFMAs; row stride = 8 mod 16
+// floats makes those reads bank-conflict free.  Weights of the block are staged as
+// [tap][ci][n][cg], read the same way.
+template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC>
+__global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
+    constexpr int NW = WM * WN, NTHR = 64 * NW;
+    constexpr int PW = TW / 4, MT = (TH / 4) * PW / WM;
+    constexpr int LH = TH + 2, LW = TW + 2;
+    constexpr int RS = LW * 16 + 8;              // floats; RS % 16 == 8
+    constexpr int COUT_T = 16 * NT * WN;
+    constexpr int NB = 9 * 16 * COUT_T;          // weight floats per 16-channel block
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sB = sA + LH * RS;
+    float* sS = sB + NB;                         // SC: [ci][n][cg]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x % p.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int g = blockIdx.y, n = blockIdx.z;
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
+        abase[mt] = (pr * 4 + (i16 >> 2)) * RS + (pc * 4 + (i16 & 3)) * 16 + kq * 4;
+    }
+    const int bbase = (kq * COUT_T + wn * NT * 16 + i16) * 4;
+
+    f32x4 acc[MT][NT];
+    f32x4 accs[SC ? MT : 1][SC ? NT : 1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (SC) accs[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+    const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4;
+    for (int cb = 0; cb < nblk; ++cb) {
+        const bool first = cb < nblk0;
+        const float* src = first ? p.src0 : p.src1;
+        const int Cs = first ? p.C0 : p.C1;
+        const int coff = (first ? cb : cb - nblk0) * 16;
+        const Aff* aff = (first && p.aff0) ? p.aff0 + (size_t)n * p.C0 + coff : nullptr;
+        // ---- stage the input tile (AdaIN applied on the fly, zero padding after it)
+        for (int idx = tid; idx < LH * LW; idx += NTHR) {
+            const int ly = idx / LW, lx = idx % LW;
+            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+            float4 v[4];
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                const float4* ptr = reinterpret_cast<const float4*>(
+                    src + ((size_t)(n * p.Hs + (gy >> p.up)) * p.Ws + (gx >> p.up)) * Cs + coff);
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) v[cg] = ptr[cg];
+                if (aff) {
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) {
+                        const Aff a0 = aff[cg * 4 + 0], a1 = aff[cg * 4 + 1], a2 = aff[cg * 4 + 2], a3 = aff[cg * 4 + 3];
+                        v[cg].x = fmaf(v[cg].x - a0.mean, a0.A, a0.B);
+                        v[cg].y = fmaf(v[cg].y - a1.mean, a1.A, a1.B);
+                        v[cg].z = fmaf(v[cg].z - a2.mean, a2.A, a2.B);
+                        v[cg].w = fmaf(v[cg].w - a3.mean, a3.A, a3.B);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) v[cg] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4* dst = reinterpret_cast<float4*>(sA + ly * RS + lx * 16);
+            dst[0] = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+            dst[1] = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+            dst[2] = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+            dst[3] = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+        }
+        // ---- stage the weights of this block (already in LDS order in HBM)
+        {
+            const float4* wsrc = reinterpret_cast<const float4*>(p.wpk + ((size_t)g * nblk + cb) * NB);
+            float4* wdst = reinterpret_cast<float4*>(sB);
+            for (int idx = tid; idx < NB / 4; idx += NTHR) wdst[idx] = wsrc[idx];
+            if (SC) {
+                const float4* ssrc = reinterpret_cast<const float4*>(p.wsc + ((size_t)g * nblk + cb) * (16 * COUT_T));
+                float4* sdst = reinterpret_cast<float4*>(sS);
+                for (int idx = tid; idx < 16 * COUT_T / 4; idx += NTHR) sdst[idx] = ssrc[idx];
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: K order (tap, cg, ci) inside the block
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * RS + (tap % 3) * 16;
+            f32x4 a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(sA + abase[mt] + toff);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                b[nt] = *reinterpret_cast<const f32x4*>(sB + tap * 16 * COUT_T + bbase + nt * 64);
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
+            if (SC && tap == 4) {  // 1x1 shortcut on the centre tap, natural channel order
+                f32x4 bs[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bs[nt] = *reinterpret_cast<const f32x4*>(sS + bbase + nt * 64);
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            accs[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], bs[nt][cg], accs[mt][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C layout: lane -> (channel = lane&15, patch row = lane>>4), reg -> patch column
+    const int prow_in_patch = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = g * COUT_T + wn * NT * 16 + nt * 16 + i16;
+        unsigned long long I1 = 0, I2 = 0;
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, scb = 0.f;
+        if (EPI == EPI_SYNTH) { e0 = p.nscale[co]; e1 = p.nbias[co]; }
+        if (EPI == EPI_DEC) { e0 = p.bias[co]; e1 = p.bn_rm[co]; e2 = p.bn_s[co]; e3 = p.bn_beta[co]; }
+        if (SC) scb = p.sc_bias[co];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
+            const int y = y0 + pr * 4 + prow_in_patch, x = x0 + pc * 4;
+            const size_t pix = (size_t)(n * p.H + y) * p.W + x;
+            float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+            if (EPI == EPI_SYNTH) {
+                const float4 nz = *reinterpret_cast<const float4*>(p.noise + pix);
+                const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = e0 * nzv[r];
+                    v[r] = lrelu((v[r] + t) + e1);
+                }
+                const float s = (v[0] + v[1]) + (v[2] + v[3]);
+                const float q = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                I1 += to_fixed(s, kStatScale1);
+                I2 += to_fixed(q, kStatScale2);
+            }
+            if (EPI == EPI_DEC) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float yv = v[r] + e0;
+                    v[r] = lrelu(fmaf(yv - e1, e2, e3));
+                    if (p.resid) {
+                        const size_t rp = p.resid_up
+                                              ? (size_t)(n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + ((x + r) >> 1)
+                                              : pix + r;
+                        v[r] = p.resid[rp * p.Cout + co] + v[r];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.out[(pix + r) * p.Cout + co] = v[r];
+            if (SC) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p.out_sc[(pix + r) * p.Cout + co] = accs[mt][nt][r] + scb;
+            }
+        }
+        if (EPI == EPI_SYNTH) {
+            I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
+            I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
+            if (lane < 16) {
+                StatPart sp; sp.s1 = I1; sp.s2 = I2;
+                p.partials[((size_t)n * p.prow + blockIdx.x * WM + wm) * p.Cout + co] = sp;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Deconvolution 4x4 stride 2 pad 1 (the reference's fused upscale).  A 16x16 output tile
+// splits into 4 parity classes (oy&1, ox&1); each is a 2x2-tap convolution over the 10x10
+// input tile with its own weights.  One wave per class, 4 patches of 4x4 outputs each.
+template <int NT>
+__global__ __launch_bounds__(256) void deconv4x4_mfma(ConvParams p) {
+    constexpr int LH = 10, LW = 10, RS = LW * 16 + 8;
+    constexpr int COUT_T = 16 * NT, NB = 16 * 16 * COUT_T;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sB = sA + LH * RS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = wave >> 1, px = wave & 1;
+    const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x % p.tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16;           // output coordinates
+    const int iy0 = y0 / 2 - 1, ix0 = x0 / 2 - 1;   // input tile origin (with halo)
+    const int g = blockIdx.y, n = blockIdx.z;
+    const int i16 = lane & 15, kq = lane >> 4;
+    int abase[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+        abase[mt] = ((mt >> 1) * 4 + (i16 >> 2) + 1) * RS + ((mt & 1) * 4 + (i16 & 3) + 1) * 16 + kq * 4;
+    const int bbase = (kq * COUT_T + i16) * 4;
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nblk = p.C0 >> 4;
+    for (int cb = 0; cb < nblk; ++cb) {
+        const Aff* aff = p.aff0 ? p.aff0 + (size_t)n * p.C0 + cb * 16 : nullptr;
+        for (int idx = tid; idx < LH * LW; idx += 256) {
+            const int ly = idx / LW, lx = idx % LW;
+            const int gy = iy0 + ly, gx = ix0 + lx;
+            float4 v[4];
+            if (gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws) {
+                const float4* ptr = reinterpret_cast<const float4*>(
+                    p.src0 + ((size_t)(n * p.Hs + gy) * p.Ws + gx) * p.C0 + cb * 16);
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) v[cg] = ptr[cg];
+                if (aff) {
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) {
+                        const Aff a0 = aff[cg * 4 + 0], a1 = aff[cg * 4 + 1], a2 = aff[cg * 4 + 2], a3 = aff[cg * 4 + 3];
+                        v[cg].x = fmaf(v[cg].x - a0.mean, a0.A, a0.B);
+                        v[cg].y = fmaf(v[cg].y - a1.mean, a1.A, a1.B);
+                        v[cg].z = fmaf(v[cg].z - a2.mean, a2.A, a2.B);
+                        v[cg].w = fmaf(v[cg].w - a3.mean, a3.A, a3.B);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) v[cg] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4* dst = reinterpret_cast<float4*>(sA + ly * RS + lx * 16);
+            dst[0] = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+            dst[1] = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+            dst[2] = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+            dst[3] = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+        }
+        {
+            const float4* wsrc = reinterpret_cast<const float4*>(p.wpk + ((size_t)g * nblk + cb) * NB);
+            float4* wdst = reinterpret_cast<float4*>(sB);
+            for (int idx = tid; idx < NB / 4; idx += 256) wdst[idx] = wsrc[idx];
+        }
+        __syncthreads();
+        // valid taps of this parity class, ascending ky then kx:
+        //   py==0: ky=1 (dy 0), ky=3 (dy -1);   py==1: ky=0 (dy +1), ky=2 (dy 0)
+#pragma unroll
+        for (int jy = 0; jy < 2; ++jy) {
+            const int ky = (py ? 0 : 1) + 2 * jy;
+            const int dy = py ? (1 - jy) : -jy;
+#pragma unroll
+            for (int jx = 0; jx < 2; ++jx) {
+                const int kx = (px ? 0 : 1) + 2 * jx;
+                const int dx = px ? (1 - jx) : -jx;
+                const int toff = dy * RS + dx * 16;
+                const int tap = ky * 4 + kx;
+                f32x4 a[4], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(sA + abase[mt] + toff);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    b[nt] = *reinterpret_cast<const f32x4*>(sB + tap * 16 * COUT_T + bbase + nt * 64);
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = g * COUT_T + nt * 16 + i16;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int oy = y0 + 2 * ((mt >> 1) * 4 + (lane >> 4)) + py;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = x0 + 2 * ((mt & 1) * 4 + r) + px;
+                p.out[((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + co] = acc[mt][nt][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Blur (depthwise 3x3, zero pad) -> AddNoise -> Bias -> LeakyReLU -> statistics.
+// One thread = one aligned quad of 4 consecutive x for 4 consecutive channels.
+__global__ __launch_bounds__(256) void post_kernel(PostParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sstat[];   // [2][C]
+    const int n = blockIdx.y;
+    const int C4 = p.C >> 2, W4 = p.W >> 2;
+    const int total = p.H * W4 * C4;
+    for (int i = threadIdx.x; i < 2 * p.C; i += 256) sstat[i] = 0ull;
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < total) {
+        const int cq = idx % C4, xq = (idx / C4) % W4, y = idx / (C4 * W4);
+        const int c = cq * 4, x0 = xq * 4;
+        const float* src = p.src + (p.src_per_sample ? (size_t)n * p.H * p.W * p.C : 0);
+        float v[4][4];   // [x][channel]
+        if (p.blur) {
+            float wk[4][9];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wk[j][t] = p.blur[(c + j) * 9 + t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[r][j] = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = y + ky - 1;
+                if (yy < 0 || yy >= p.H) continue;
+                float4 row[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int xx = x0 - 1 + k;
+                    row[k] = (xx >= 0 && xx < p.W)
+                                 ? *reinterpret_cast<const float4*>(src + ((size_t)yy * p.W + xx) * p.C + c)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = x0 + r + kx - 1;
+                        if (xx < 0 || xx >= p.W) continue;   // skipped taps == +0
+                        const float4 t = row[r + kx];
+                        v[r][0] = fmaf(t.x, wk[0][ky * 3 + kx], v[r][0]);
+                        v[r][1] = fmaf(t.y, wk[1][ky * 3 + kx], v[r][1]);
+                        v[r][2] = fmaf(t.z, wk[2][ky * 3 + kx], v[r][2]);
+                        v[r][3] = fmaf(t.w, wk[3][ky * 3 + kx], v[r][3]);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 t = *reinterpret_cast<const float4*>(src + ((size_t)y * p.W + x0 + r) * p.C + c);
+                v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+            }
+        }
+        const float4 nz = *reinterpret_cast<const float4*>(p.noise + ((size_t)n * p.H + y) * p.W + x0);
+        const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
+        const float4 sf = *reinterpret_cast<const float4*>(p.nscale + c);
+        const float4 nb = *reinterpret_cast<const float4*>(p.nbias + c);
+        const float sfv[4] = {sf.x, sf.y, sf.z, sf.w}, nbv[4] = {nb.x, nb.y, nb.z, nb.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = sfv[j] * nzv[r];
+                v[r][j] = lrelu((v[r][j] + t) + nbv[j]);
+            }
+            *reinterpret_cast<float4*>(p.out + (((size_t)n * p.H + y) * p.W + x0 + r) * p.C + c) =
+                make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
+            const float q = fmaf(v[3][j], v[3][j], fmaf(v[2][j], v[2][j], fmaf(v[1][j], v[1][j], v[0][j] * v[0][j])));
+            atomicAdd(&sstat[c + j], to_fixed(s, kStatScale1));
+            atomicAdd(&sstat[p.C + c + j], to_fixed(q, kStatScale2));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.C; i += 256) {
+        StatPart sp; sp.s1 = sstat[i]; sp.s2 = sstat[p.C + i];
+        p.partials[((size_t)n * p.prow + blockIdx.x) * p.C + i] = sp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Sum the fixed-point partials and fold InstanceNorm(eps 1e-5) with the AdaIN style.
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
+    __shared__ unsigned long long sh[2][4][64];
+    const int n = blockIdx.y;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    unsigned long long I1 = 0, I2 = 0;
+    if (c < p.C) {
+        const StatPart* base = p.partials + (size_t)n * p.prow * p.C + c;
+        for (int r = rg; r < p.prow; r += 4) {
+            const StatPart sp = base[(size_t)r * p.C];
+            I1 += sp.s1; I2 += sp.s2;
+        }
+    }
+    sh[0][rg][cl] = I1; sh[1][rg][cl] = I2;
+    __syncthreads();
+    if (rg == 0 && c < p.C) {
+        I1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+        I2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+        const double inv_hw = 1.0 / (double)p.HW;   // HW is a power of two
+        const double m = (double)(long long)I1 * (1.0 / kStatScale1) * inv_hw;
+        const double e2 = (double)(long long)I2 * (1.0 / kStatScale2) * inv_hw;
+        double var = fma(-m, m, e2);
+        if (!(var > 0.0)) var = 0.0;
+        const float mean_f = (float)m, var_f = (float)var;
+        const float inv = 1.0f / sqrtf(var_f + 1e-5f);
+        const float gsc = p.gamma[c] * inv;
+        const float* st = p.style + (size_t)n * p.style_stride;
+        const float s1 = st[c] + 1.0f;
+        Aff a;
+        a.mean = mean_f;
+        a.A = gsc * s1;
+        a.B = fmaf(p.beta[c], s1, st[p.C + c]);
+        a.pad = 0.0f;
+        p.aff[(size_t)n * p.C + c] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Mapping network pieces.  Every output is one k-ordered fmaf chain (canonical order).
+__global__ void pixelnorm_kernel(const float* z, float* out, int n, int L) {
+    // one wave per sample: lane 0 runs the chain, all lanes scale
+    const int s = blockIdx.x;
+    const float* zs = z + (size_t)s * L;
+    __shared__ float rn;
+    if (threadIdx.x == 0) {
+        float ss = 0.0f;
+        for (int k = 0; k < L; ++k) ss = fmaf(zs[k], zs[k], ss);
+        rn = 1.0f / sqrtf(ss / (float)L + 1e-8f);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < L; k += blockDim.x) out[(size_t)s * L + k] = zs[k] * rn;
+}
+
+__global__ __launch_bounds__(64) void dense_kernel(const float* x, const float* WT, const float* b, float* y,
+                                                   int K, int J, int act) {
+    const int j = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
+    if (j >= J) return;
+    const float* xs = x + (size_t)s * K;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) acc = fmaf(xs[k], WT[(size_t)k * J + j], acc);
+    float v = acc + b[j];
+    y[(size_t)s * J + j] = act ? lrelu(v) : v;
+}
+
+// all style affines in one launch: column j belongs to style layer col_layer[j];
+// x_k = latent_avg[k]*(1-psi_l) + w[k]*psi_l (truncation lerp, reference :158-163)
+__global__ __launch_bounds__(64) void styles_kernel(const float* w, const float* avg, const float* psi,
+                                                    const float* WT, const float* b, const int* col_layer,
+                                                    float* styles, int K, int J) {
+    const int j = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
+    if (j >= J) return;
+    const float ps = psi[col_layer[j]];
+    const float om = 1.0f - ps;
+    const float* ws = w + (size_t)s * K;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) {
+        const float t0 = avg[k] * om;
+        const float t1 = ws[k] * ps;
+        acc = fmaf(t0 + t1, WT[(size_t)k * J + j], acc);
+    }
+    styles[(size_t)s * J + j] = acc + b[j];
+}
+
+// ------------------------------------------------------------------------------------------
+// toRGB (1x1 conv + bias) and the uint8 image of _transform_gan_back.
+__global__ __launch_bounds__(256) void torgb_kernel(const float* x, const Aff* aff, const float* w, const float* b,
+                                                    float* rgb, uint8_t* img, int HW, int C, int nc) {
+    const int n = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const float* px = x + ((size_t)n * HW + pix) * C;
+    const Aff* a = aff + (size_t)n * C;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; c += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(px + c);
+        const float f[4] = {fmaf(v.x - a[c].mean, a[c].A, a[c].B), fmaf(v.y - a[c + 1].mean, a[c + 1].A, a[c + 1].B),
+                            fmaf(v.z - a[c + 2].mean, a[c + 2].A, a[c + 2].B), fmaf(v.w - a[c + 3].mean, a[c + 3].A, a[c + 3].B)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < nc) acc[o] = fmaf(f[j], w[o * C + c + j], acc[o]);
+    }
+    for (int o = 0; o < nc; ++o) {
+        const float v = acc[o] + b[o];
+        if (rgb) rgb[((size_t)n * nc + o) * HW + pix] = v;
+        if (img) {
+            float t = (v + 1.0f) * 0.5f;
+            t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+            t = 255.0f * t;
+            img[((size_t)n * HW + pix) * nc + o] = (uint8_t)t;
+        }
+    }
+}
+
+// feature export: NHWC (+AdaIN) -> NCHW fp32, the layout the reference returns
+__global__ __launch_bounds__(256) void export_nchw_kernel(const float* x, const Aff* aff, float* out, int HW, int C) {
+    __shared__ float tile[64][17];
+    const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 16;
+    {   // read 64 pixels x 16 channels, channel fastest
+        const int pl = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 4;
+        if (p0 + pl < HW) {
+            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * HW + p0 + pl) * C + c0 + cq);
+            float f[4] = {v.x, v.y, v.z, v.w};
+            if (aff) {
+                const Aff* a = aff + (size_t)n * C + c0 + cq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = fmaf(f[j] - a[j].mean, a[j].A, a[j].B);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[pl][cq + j] = f[j];
+        }
+    }
+    __syncthreads();
+    {   // write pixel fastest
+        const int pl = threadIdx.x & 63, cr = threadIdx.x >> 6;
+        if (p0 + pl < HW)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = cr * 4 + k;
+                out[((size_t)n * C + c0 + c) * HW + p0 + pl] = tile[pl][c];
+            }
+    }
+}
+
+// feature import: NCHW fp32 -> NHWC
+__global__ __launch_bounds__(256) void import_nhwc_kernel(const float* in, float* out, int HW, int C) {
+    __shared__ float tile[64][17];
+    const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 16;
+    {
+        const int pl = threadIdx.x & 63, cr = threadIdx.x >> 6;
+        if (p0 + pl < HW)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = cr * 4 + k;
+                tile[pl][c] = in[((size_t)n * C + c0 + c) * HW + p0 + pl];
+            }
+    }
+    __syncthreads();
+    {
+        const int pl = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 4;
+        if (p0 + pl < HW)
+            *reinterpret_cast<float4*>(out + ((size_t)n * HW + p0 + pl) * C + c0 + cq) =
+                make_float4(tile[pl][cq], tile[pl][cq + 1], tile[pl][cq + 2], tile[pl][cq + 3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Final conv3x3 (in_c -> NCLS classes) + bias + argmax (first maximum wins).  NCLS is tiny
+// (2 in the reference), so the contraction runs on the vector ALU: one thread per pixel,
+// input tile staged in LDS, weights through uniform (scalar) loads.
+template <int NCLS>
+__global__ __launch_bounds__(256) void final_conv_kernel(const float* src0, int C0, const float* src1, int C1,
+                                                         const float* wpk, const float* bias, float* logits,
+                                                         uint8_t* mask, int H, int W, int tiles_x) {
+    constexpr int LW = 18, CP = 20, RS = 384;   // pixel stride 20 floats, row stride 384 floats
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x, n = blockIdx.y;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int ly = tid >> 4, lx = tid & 15;
+    float acc[NCLS];
+#pragma unroll
+    for (int o = 0; o < NCLS; ++o) acc[o] = 0.0f;
+    const int nblk0 = C0 >> 4, nblk = (C0 + C1) >> 4;
+    for (int cb = 0; cb < nblk; ++cb) {
+        const bool first = cb < nblk0;
+        const float* src = first ? src0 : src1;
+        const int Cs = first ? C0 : C1;
+        const int coff = (first ? cb : cb - nblk0) * 16;
+        for (int idx = tid; idx < 18 * LW; idx += 256) {
+            const int sy = idx / LW, sx = idx % LW;
+            const int gy = y0 - 1 + sy, gx = x0 - 1 + sx;
+            float4 v[4];
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const float4* ptr = reinterpret_cast<const float4*>(src + ((size_t)(n * H + gy) * W + gx) * Cs + coff);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = ptr[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4* dst = reinterpret_cast<float4*>(smem + sy * RS + sx * CP);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k] = v[k];
+        }
+        __syncthreads();
+        const float* wb = wpk + (size_t)cb * 9 * 16 * NCLS;   // [tap][c][NCLS]
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float4* a4 = reinterpret_cast<const float4*>(smem + (ly + tap / 3) * RS + (lx + tap % 3) * CP);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 a = a4[k];
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int o = 0; o < NCLS; ++o) acc[o] = fmaf(av[j], wb[(tap * 16 + k * 4 + j) * NCLS + o], acc[o]);
+            }
+        }
+        __syncthreads();
+    }
+    const int y = y0 + ly, x = x0 + lx;
+    const size_t pix = (size_t)y * W + x, HW = (size_t)H * W;
+    int best = 0;
+    float bv = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NCLS; ++o) {
+        const float v = acc[o] + bias[o];
+        if (logits) logits[((size_t)n * NCLS + o) * HW + pix] = v;
+        if (o == 0 || v > bv) { bv = v; best = o; }
+    }
+    if (mask) mask[(size_t)n * HW + pix] = (uint8_t)best;
+}
+
+// ========================================================================================
+// host-side launchers
+
+int conv_cout_tile(int H, int Cout) {
+    if (H == 4) return Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16));
+    if (H == 8) return Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16);
+    return Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16);
+}
+
+static int conv_wm(int H, int Cout) {
+    if (H == 4) return 1;
+    if (H == 8) return conv_cout_tile(H, Cout) == 16 ? 4 : 2;
+    return 4;
+}
+
+int post_prow(int H, int W, int C) { return (H * (W / 4) * (C / 4) + 255) / 256; }
+
+template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC>
+static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
+    constexpr int COUT_T = 16 * NT * WN;
+    constexpr int RS = (TW + 2) * 16 + 8;
+    constexpr size_t lds = sizeof(float) * ((TH + 2) * RS + 9 * 16 * COUT_T + (SC ? 16 * COUT_T : 0));
+    auto kern = conv3x3_mfma<TH, TW, WM, WN, NT, EPI, SC>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    ConvParams q = p;
+    q.tiles_x = p.W / TW;
+    dim3 grid((p.H / TH) * (p.W / TW), p.Cout / COUT_T, n);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, q);
+    return hipGetLastError();
+}
+
+template <int TH, int TW, int WM, int WN, int NT>
+static hipError_t launch_conv_e(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
+    if (sc) {
+        if (epi != EPI_DEC) return hipErrorInvalidValue;
+        return launch_conv_t<TH, TW, WM, WN, NT, EPI_DEC, true>(p, n, s);
+    }
+    switch (epi) {
+        case EPI_RAW: return launch_conv_t<TH, TW, WM, WN, NT, EPI_RAW, false>(p, n, s);
+        case EPI_SYNTH: return launch_conv_t<TH, TW, WM, WN, NT, EPI_SYNTH, false>(p, n, s);
+        case EPI_DEC: return launch_conv_t<TH, TW, WM, WN, NT, EPI_DEC, false>(p, n, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// statistic partial rows written per sample for this layer geometry (tiles * WM)
+int conv_stat_rows(int H, int W, int Cout) {
+    const int th = H >= 16 ? 16 : H;
+    return (H / th) * (W / th) * conv_wm(H, Cout);
+}
+
+hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
+    if (p.H != p.W || (p.H & (p.H - 1)) || p.H < 4 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
+    ConvParams q = p;
+    q.prow = conv_stat_rows(p.H, p.W, p.Cout);
+    const int ct = conv_cout_tile(p.H, p.Cout);
+    if (p.H == 4) {
+        if (ct == 128) return launch_conv_e<4, 4, 1, 4, 2>(q, epi, sc, n, s);
+        if (ct == 64) return launch_conv_e<4, 4, 1, 4, 1>(q, epi, sc, n, s);
+        if (ct == 32) return launch_conv_e<4, 4, 1, 2, 1>(q, epi, sc, n, s);
+        return launch_conv_e<4, 4, 1, 1, 1>(q, epi, sc, n, s);
+    }
+    if (p.H == 8) {
+        if (ct == 64) return launch_conv_e<8, 8, 2, 2, 2>(q, epi, sc, n, s);
+        if (ct == 32) return launch_conv_e<8, 8, 2, 2, 1>(q, epi, sc, n, s);
+        return launch_conv_e<8, 8, 4, 1, 1>(q, epi, sc, n, s);
+    }
+    if (ct == 64) return launch_conv_e<16, 16, 4, 1, 4>(q, epi, sc, n, s);
+    if (ct == 32) return launch_conv_e<16, 16, 4, 1, 2>(q, epi, sc, n, s);
+    return launch_conv_e<16, 16, 4, 1, 1>(q, epi, sc, n, s);
+}
+
+template <int NT>
+static hipError_t launch_deconv_t(const ConvParams& p, int n, hipStream_t s) {
+    constexpr int COUT_T = 16 * NT;
+    constexpr size_t lds = sizeof(float) * (10 * (10 * 16 + 8) + 16 * 16 * COUT_T);
+    auto kern = deconv4x4_mfma<NT>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    ConvParams q = p;
+    q.tiles_x = p.W / 16;
+    dim3 grid((p.H / 16) * (p.W / 16), p.Cout / COUT_T, n);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q);
+    return hipGetLastError();
+}
+
+int deconv_cout_tile(int Cout) { return Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16); }
+
+hipError_t launch_deconv4x4(const ConvParams& p, int n, hipStream_t s) {
+    if (p.H != 2 * p.Hs || p.W != 2 * p.Ws || p.H % 16 || p.W % 16 || p.Cout % 16 || p.C0 % 16 || p.C1) return hipErrorInvalidValue;
+    const int ct = deconv_cout_tile(p.Cout);
+    if (ct == 64) return launch_deconv_t<4>(p, n, s);
+    if (ct == 32) return launch_deconv_t<2>(p, n, s);
+    return launch_deconv_t<1>(p, n, s);
+}
+
+hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
+    if (p.W % 4 || p.C % 4) return hipErrorInvalidValue;
+    PostParams q = p;
+    q.prow = post_prow(p.H, p.W, p.C);
+    dim3 grid(q.prow, n);
+    hipLaunchKernelGGL(post_kernel, grid, dim3(256), sizeof(unsigned long long) * 2 * p.C, s, q);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s) {
+    dim3 grid((p.C + 63) / 64, n);
+    hipLaunchKernelGGL(finalize_kernel, grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_t s) {
+    hipLaunchKernelGGL(pixelnorm_kernel, dim3(n), dim3(64), 0, s, z, out, n, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense(const float* x, const float* WT, const float* b, float* y, int n, int K, int J, int act, hipStream_t s) {
+    hipLaunchKernelGGL(dense_kernel, dim3((J + 63) / 64, n), dim3(64), 0, s, x, WT, b, y, K, J, act);
+    return hipGetLastError();
+}
+
+hipError_t launch_styles(const float* w, const float* avg, const float* psi, const float* WT, const float* b,
+                         const int* col_layer, float* styles, int n, int K, int J, hipStream_t s) {
+    hipLaunchKernelGGL(styles_kernel, dim3((J + 63) / 64, n), dim3(64), 0, s, w, avg, psi, WT, b, col_layer, styles, K, J);
+    return hipGetLastError();
+}
+
+hipError_t launch_torgb(const float* x, const Aff* aff, const float* w, const float* b, float* rgb, uint8_t* img,
+                        int n, int H, int W, int C, int nc, hipStream_t s) {
+    if (nc > 4 || C % 4) return hipErrorInvalidValue;
+    const int HW = H * W;
+    hipLaunchKernelGGL(torgb_kernel, dim3((HW + 255) / 256, n), dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_nchw(const float* x, const Aff* aff, float* out, int n, int H, int W, int C, hipStream_t s) {
+    const int HW = H * W;
+    hipLaunchKernelGGL(export_nchw_kernel, dim3((HW + 63) / 64, C / 16, n), dim3(256), 0, s, x, aff, out, HW, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_import_nhwc(const float* in, float* out, int n, int H, int W, int C, hipStream_t s) {
+    const int HW = H * W;
+    hipLaunchKernelGGL(import_nhwc_kernel, dim3((HW + 63) / 64, C / 16, n), dim3(256), 0, s, in, out, HW, C);
+    return hipGetLastError();
+}
+
+template <int NCLS>
+static hipError_t launch_final_t(const float* src0, int C0, const float* src1, int C1, const float* wpk, const float* bias,
+                                 float* logits, uint8_t* mask, int n, int H, int W, hipStream_t s) {
+    const size_t lds = sizeof(float) * 18 * 384;
+    hipLaunchKernelGGL(final_conv_kernel<NCLS>, dim3((H / 16) * (W / 16), n), dim3(256), lds, s, src0, C0, src1, C1, wpk,
+                       bias, logits, mask, H, W, W / 16);
+    return hipGetLastError();
+}
+
+hipError_t launch_final_conv(const float* src0, int C0, const float* src1, int C1, const float* wpk, const float* bias,
+                             float* logits, uint8_t* mask, int n, int H, int W, int ncls, hipStream_t s) {
+    if (H % 16 || W % 16 || C0 % 16 || C1 % 16) return hipErrorInvalidValue;
+    switch (ncls) {
+        case 1: return launch_final_t<1>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
+        case 2: return launch_final_t<2>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
+        case 3: return launch_final_t<3>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
+        case 4: return launch_final_t<4>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
+        case 5: return launch_final_t<5>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
+        case 6: return launch_final_t<6>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
+        case 7: return launch_final_t<7>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
+        case 8: return launch_final_t<8>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace gsa
