@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: synthetic (image, mask) pairs/sec of the `generate` hot path --
+FFHQ-1024 StyleGAN synthesis + 2-class decoder, fp32, batch 8 per GPU (BASELINE.json
+configs[1]); N GPUs = N processes, each its own batch (weak scaling), ONE RCCL gather of the
+uint8 pairs to rank 0 per step.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the bench contract in DESIGN.md)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GFLOP_PER_SAMPLE = {"ffhq": 126.44, "cars": 85.52, "bedrooms": 55.51}
+MB_PER_SAMPLE = {"ffhq": 1440.0, "cars": 623.2, "bedrooms": 234.4}
+PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(gan, seconds_budget=25.0):
+    """Stand-in for the reference's mxnet-CPU path (MXNet is not installable here): the
+    semantic torch-CPU restatement (oneDNN convolutions), batch 1, all host cores."""
+    import torch
+    from gan_segmentation_amd import weights as W
+    from oracle import ref_semantic as S
+    mr = W.GAN_MAX_RES_LOG2[gan]
+    gcfg, dcfg = W.generator_config(mr), W.decoder_config(mr)
+    gp, dp = W.synthetic_generator_params(gcfg, seed=2), W.synthetic_decoder_params(dcfg, seed=3)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    times = []
+    t_start = time.perf_counter()
+    i = 0
+    while True:
+        z, noise = W.synthetic_inputs(gcfg, 1, seed_z=100 + i, seed_noise=200 + i)
+        t0 = time.perf_counter()
+        S.generate(gcfg, gp, dcfg, dp, z, noise)
+        dt = time.perf_counter() - t0
+        if i > 0:       # first sample is the warm-up
+            times.append(dt)
+        i += 1
+        if (len(times) >= 1 and time.perf_counter() - t_start > seconds_budget) or len(times) >= 16:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%s %d^2 synthesis+decoder, batch 1, %d samples after 1 warm-up, median; torch-CPU fp32 "
+                      "(oneDNN) restatement oracle/ref_semantic.py standing in for the reference's mxnet-CPU path"
+                      % (gan, 2 ** mr, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gan", default="ffhq", choices=("ffhq", "cars", "bedrooms"))
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="per-layer kernel breakdown on stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gan_segmentation_amd import dist as gdist
+    from gan_segmentation_amd import weights as W
+    from gan_segmentation_amd.image_generator import ImageGenerator
+
+    rank, world, local_rank = gdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the generate path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    mr = W.GAN_MAX_RES_LOG2[args.gan]
+    gcfg, dcfg = W.generator_config(mr), W.decoder_config(mr)
+    gp, dp = W.synthetic_generator_params(gcfg, seed=2), W.synthetic_decoder_params(dcfg, seed=3)
+    gen = ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[local_rank], batch_size=args.batch)
+    B = args.batch
+    # per-rank inputs keyed by global sample index, resident in HBM before the timed region
+    z, noise = W.synthetic_inputs(gcfg, B, seed_z=1000 + rank, seed_noise=2000 + rank)
+    z = torch.from_numpy(z).to(dev)
+    noise = [torch.from_numpy(a).to(dev) for a in noise]
+    ctx = gen.netG._model.ctx
+
+    def step():
+        img, mask = gen.generate_batch(z, noise)
+        if world > 1:
+            img, mask = gdist.gather_pairs(img, mask)
+        return img, mask
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile_enable(2 if args.layers else 1)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    entries = ctx.profile_entries()
+    ctx.profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / dt
+        entries.sort(key=lambda e: -e["ms"])
+        top = entries[0]
+        kms = sum(e["ms"] for e in entries)
+        ach = top["flops"] / (top["ms"] * 1e-3) / 1e12 if top["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": top["name"], "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
+                    "avg_launch_ms": round(top["ms"] / max(1, top["launches"]), 4),
+                    "launches": top["launches"], "traffic": None}
+        out = {
+            "metric": "synthetic (image,mask) pairs/sec, %s-%d StyleGAN+decoder" % (args.gan.upper(), 2 ** mr),
+            "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "stylegan-%s %d^2 synthesis + %d-class decoder, batch=%d per GPU, fp32 "
+                                   "(BASELINE.json configs[1]); synthetic weights/latents/noise; (img u8, mask u8) "
+                                   "resident on rank 0" % (args.gan, 2 ** mr, dcfg["num_classes"], B),
+                       "global_batch": world * B, "parallelism": "dp%d" % world},
+            "roofline": roofline,
+            "whole_path": {
+                "fp32_tflops": round(GFLOP_PER_SAMPLE[args.gan] * value / 1e3, 2),
+                "fp32_frac_of_peak": round(GFLOP_PER_SAMPLE[args.gan] * value / 1e3 / world / PEAK_FP32_TFLOPS, 4),
+                "algorithmic_hbm_gbs": round(MB_PER_SAMPLE[args.gan] * value / 1e3, 1),
+                "hbm_frac_of_peak": round(MB_PER_SAMPLE[args.gan] * value / 1e3 / world / PEAK_HBM_GBS, 4),
+                "kernel_ms_per_step": round(kms / args.steps, 3),
+            },
+            "kernels": [{"name": e["name"], "ms_per_step": round(e["ms"] / args.steps, 3),
+                         "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else 0.0,
+                         "gbs": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 1) if e["ms"] > 0 else 0.0}
+                        for e in entries[:8]],
+        }
+        if args.layers:
+            for e in entries:
+                print("%-70s %8.3f ms/step %7.2f TF/s %8.1f GB/s" % (
+                    e["name"], e["ms"] / args.steps, e["flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] else 0,
+                    e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["ms"] else 0), file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.gan)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -195,7 +195,7 @@ class Context:
 
     # -- measurement ----------------------------------------------------------------------
     def profile_enable(self, on=True):
-        self._check(self.api.profile_enable(self._h, 1 if on else 0), "profile_enable")
+        self._check(self.api.profile_enable(self._h, int(on)), "profile_enable")
 
     def profile_reset(self):
         self._check(self.api.profile_reset(self._h), "profile_reset")

@@ -104,6 +104,7 @@ struct gsa_ctx {
     Aff* aff1 = nullptr;
     Aff* aff2[kMaxLevels] = {nullptr};
     StatPart* partials = nullptr;
+    StatPart* stat_acc = nullptr;
     float* din[kMaxLevels] = {nullptr};
     float* cvt[kMaxLevels] = {nullptr};
     float *ya[kMaxLevels] = {nullptr}, *scb[kMaxLevels] = {nullptr}, *prev[kMaxLevels] = {nullptr};
@@ -687,6 +688,8 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
         if (int rc = dev_alloc(c, N * maxact, &c->x1, T)) return rc;
         if (int rc = dev_alloc(c, N * maxC, &c->aff1, T)) return rc;
         if (int rc = dev_alloc(c, N * prow_elems, &c->partials, T)) return rc;
+        if (int rc = dev_alloc(c, N * maxC, &c->stat_acc, T)) return rc;
+        HIP_TRY(hipMemset(c->stat_acc, 0, N * maxC * sizeof(StatPart)));
     }
     if (c->d_ready) {
         for (int i = 0; i < c->d_n; ++i) {
@@ -775,7 +778,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 prow = conv_stat_rows(R, R, C);
             }
             FinalizeParams fp{};
-            fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C;
+            fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C; fp.acc = c->stat_acc;
             fp.style = c->styles + B.style_off[k]; fp.style_stride = c->style_cols;
             fp.gamma = B.gamma[k]; fp.beta = B.beta[k];
             fp.aff = k == 0 ? c->aff1 : c->aff2[l];

@@ -433,42 +433,58 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Sum the fixed-point partials and fold InstanceNorm(eps 1e-5) with the AdaIN style.
-__global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
-    __shared__ unsigned long long sh[2][4][64];
+// Sum the fixed-point partial rows into acc[n][C] (64-bit integer atomics: order independent,
+// hence deterministic), many blocks per (sample, channel group).
+__global__ __launch_bounds__(256) void stat_reduce_kernel(const StatPart* partials, int prow, int C, StatPart* acc,
+                                                          int rows_per_block) {
+    __shared__ unsigned long long sh[2][256];
     const int n = blockIdx.y;
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int cblk = C >= 64 ? 64 : C, nrg = 256 / cblk;
+    const int cl = threadIdx.x % cblk, rg = threadIdx.x / cblk;
     const int c = blockIdx.x * 64 + cl;
     unsigned long long I1 = 0, I2 = 0;
-    if (c < p.C) {
-        const StatPart* base = p.partials + (size_t)n * p.prow * p.C + c;
-        for (int r = rg; r < p.prow; r += 4) {
-            const StatPart sp = base[(size_t)r * p.C];
+    if (rg < nrg && c < C) {
+        const int r0 = blockIdx.z * rows_per_block;
+        const int r1 = min(prow, r0 + rows_per_block);
+        const StatPart* base = partials + (size_t)n * prow * C + c;
+        for (int r = r0 + rg; r < r1; r += nrg) {
+            const StatPart sp = base[(size_t)r * C];
             I1 += sp.s1; I2 += sp.s2;
         }
     }
-    sh[0][rg][cl] = I1; sh[1][rg][cl] = I2;
+    sh[0][threadIdx.x] = I1; sh[1][threadIdx.x] = I2;
     __syncthreads();
-    if (rg == 0 && c < p.C) {
-        I1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
-        I2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
-        const double inv_hw = 1.0 / (double)p.HW;   // HW is a power of two
-        const double m = (double)(long long)I1 * (1.0 / kStatScale1) * inv_hw;
-        const double e2 = (double)(long long)I2 * (1.0 / kStatScale2) * inv_hw;
-        double var = fma(-m, m, e2);
-        if (!(var > 0.0)) var = 0.0;
-        const float mean_f = (float)m, var_f = (float)var;
-        const float inv = 1.0f / sqrtf(var_f + 1e-5f);
-        const float gsc = p.gamma[c] * inv;
-        const float* st = p.style + (size_t)n * p.style_stride;
-        const float s1 = st[c] + 1.0f;
-        Aff a;
-        a.mean = mean_f;
-        a.A = gsc * s1;
-        a.B = fmaf(p.beta[c], s1, st[p.C + c]);
-        a.pad = 0.0f;
-        p.aff[(size_t)n * p.C + c] = a;
+    if (rg == 0 && c < C) {
+        for (int k = 1; k < nrg; ++k) { I1 += sh[0][k * cblk + cl]; I2 += sh[1][k * cblk + cl]; }
+        atomicAdd(&acc[(size_t)n * C + c].s1, I1);
+        atomicAdd(&acc[(size_t)n * C + c].s2, I2);
     }
+}
+
+// Fold InstanceNorm(eps 1e-5) with the AdaIN style; consumes and clears acc.
+__global__ __launch_bounds__(64) void finalize_kernel(FinalizeParams p) {
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= p.C) return;
+    StatPart* ap = p.acc + (size_t)n * p.C + c;
+    const unsigned long long I1 = ap->s1, I2 = ap->s2;
+    ap->s1 = 0ull; ap->s2 = 0ull;
+    const double inv_hw = 1.0 / (double)p.HW;   // HW is a power of two
+    const double m = (double)(long long)I1 * (1.0 / kStatScale1) * inv_hw;
+    const double e2 = (double)(long long)I2 * (1.0 / kStatScale2) * inv_hw;
+    double var = fma(-m, m, e2);
+    if (!(var > 0.0)) var = 0.0;
+    const float mean_f = (float)m, var_f = (float)var;
+    const float inv = 1.0f / sqrtf(var_f + 1e-5f);
+    const float gsc = p.gamma[c] * inv;
+    const float* st = p.style + (size_t)n * p.style_stride;
+    const float s1 = st[c] + 1.0f;
+    Aff a;
+    a.mean = mean_f;
+    a.A = gsc * s1;
+    a.B = fmaf(p.beta[c], s1, st[p.C + c]);
+    a.pad = 0.0f;
+    p.aff[(size_t)n * p.C + c] = a;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -787,8 +803,13 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
 }
 
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s) {
+    const int rpb = 256;
+    dim3 rgrid((p.C + 63) / 64, n, (p.prow + rpb - 1) / rpb);
+    hipLaunchKernelGGL(stat_reduce_kernel, rgrid, dim3(256), 0, s, p.partials, p.prow, p.C, p.acc, rpb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
     dim3 grid((p.C + 63) / 64, n);
-    hipLaunchKernelGGL(finalize_kernel, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(finalize_kernel, grid, dim3(64), 0, s, p);
     return hipGetLastError();
 }
 

@@ -1,0 +1,74 @@
+"""Batch sharding across the GPUs of one node: one process per GPU, ``torch.distributed``
+over RCCL (backend "nccl" on ROCm) or gloo (CPU tests).
+
+The reference shards a batch over its ``ctx`` list with ``split_and_load(even_split=False)``
+and gathers through host memory (reference image_generator.py:95-114).  Samples are
+independent given (z_i, noise_i), so here rank r simply owns a contiguous slice of the global
+sample indices and the only exchange is ONE gather of the uint8 results to rank 0 per batch
+(4 MiB per FFHQ sample: 3 MiB image + 1 MiB mask, fused into a single buffer per rank).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total, world_size, rank):
+    """Contiguous slice [lo, hi) of ``total`` samples owned by ``rank`` -- the slicing of
+    ``split_and_load(even_split=False)``: the first ``total % world`` ranks get one extra."""
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def pack_pairs(img, mask):
+    """(n,R,R,3) u8 + (n,R,R) u8 -> one (n, R*R*4) u8 buffer: a single message per rank."""
+    n = img.shape[0]
+    return torch.cat([img.reshape(n, -1), mask.reshape(n, -1)], dim=1).contiguous()
+
+
+def unpack_pairs(buf, R, channels=3):
+    n = buf.shape[0]
+    img = buf[:, :R * R * channels].reshape(n, R, R, channels)
+    mask = buf[:, R * R * channels:].reshape(n, R, R)
+    return img, mask
+
+
+def gather_pairs(img, mask, counts=None, dst=0, group=None):
+    """Gather every rank's (img, mask) to ``dst`` with one collective.  ``counts[r]`` = samples
+    of rank r (defaults to equal shards).  Returns (img, mask) in global sample order on ``dst``
+    and (None, None) elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return img, mask
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    R, ch = img.shape[1], img.shape[3]
+    n = img.shape[0]
+    if counts is None:
+        counts = [n] * world
+    nmax = max(counts)
+    buf = pack_pairs(img, mask)
+    if n < nmax:   # ragged last batch: pad to the common message size
+        pad = torch.zeros((nmax - n, buf.shape[1]), dtype=buf.dtype, device=buf.device)
+        buf = torch.cat([buf, pad], dim=0)
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst, group=group)
+    if rank != dst:
+        return None, None
+    parts = [unpack_pairs(o[:c], R, ch) for o, c in zip(out, counts)]
+    return torch.cat([p[0] for p in parts], dim=0), torch.cat([p[1] for p in parts], dim=0)

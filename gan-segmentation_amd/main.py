@@ -1,0 +1,75 @@
+"""``python -m gan_segmentation_amd.main generate`` -- the `generate` action of reference
+main.py:75-104 with the same ``config.yml`` keys (reference config.yml.example:1-8).
+
+Writes ``img_%06d.jpg`` (RGB image; the reference flips to BGR only because cv2 expects it)
+and ``mask_%06d.png`` (single channel, class index) into BASE_DIR/dataset/train_generated.
+With torchrun (one process per GPU) the sample indices are sharded across ranks and every rank
+writes its own files -- no collective is needed when the sink is the filesystem.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import yaml
+
+
+def load_config_file(path):
+    with open(path) as f:
+        return yaml.safe_load(f)   # reference utils.py:112-115
+
+
+def generate(cfg, limit=None):
+    import torch
+    from PIL import Image
+    from . import dist as gdist
+    from .image_generator import ImageGenerator
+    from .seg_solver import SegSolver
+    from .weights import GAN_MAX_RES_LOG2
+
+    rank, world, local_rank = gdist.init_from_env()
+    root_dir, gan, gan_dir = cfg["BASE_DIR"], cfg["GAN"], cfg["GAN_DIR"]
+    gpu_ids = list(cfg["GAN_GPU_IDS"])
+    gpu = gpu_ids[local_rank % len(gpu_ids)] if world == 1 and gpu_ids else local_rank
+    n_generate = cfg.get("GENERATE_NUM", 10000) if limit is None else limit
+    batch = cfg["GAN_BATCH_SIZE_PER_GPU"]
+
+    solver = SegSolver(GAN_MAX_RES_LOG2[gan], os.path.join(root_dir, "data"), os.path.join(root_dir, "checkpoints"),
+                       gpu_ids=[gpu], keep_weights=False)
+    if not solver.is_trained:
+        print("train Decoder first!")   # reference main.py:82-84
+        return -1
+    netG = ImageGenerator(gpu_ids=[gpu], gan_dir=gan_dir, gan=gan, batch_size=batch)
+    netG.attach_decoder(solver.cfg, solver.net)
+    dst_dir = os.path.join(root_dir, "dataset", "train_generated")
+    os.makedirs(dst_dir, exist_ok=True)
+
+    lo, hi = gdist.shard_bounds(n_generate, world, rank)
+    index = lo
+    while index < hi:
+        bs = min(batch, hi - index)
+        img, mask = netG.generate_batch(netG.draw_latents(bs))
+        torch.cuda.synchronize()
+        img, mask = img.cpu().numpy(), mask.cpu().numpy()
+        for i in range(bs):
+            Image.fromarray(img[i], "RGB").save(os.path.join(dst_dir, "img_%06d.jpg" % (index + i)), quality=95)
+            Image.fromarray(mask[i], "L").save(os.path.join(dst_dir, "mask_%06d.png" % (index + i)))
+        index += bs
+    return 0
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("action", nargs="?", choices=("annotation", "train", "evaluate", "generate"), default="generate")
+    ap.add_argument("--config", default="config.yml")
+    ap.add_argument("--limit", type=int, default=None, help="override GENERATE_NUM")
+    args = ap.parse_args(argv)
+    if args.action != "generate":
+        print("only the `generate` action is implemented by the MI355X path (SURVEY.md section 8)")
+        return 2
+    np.random.seed(0)
+    return generate(load_config_file(args.config), args.limit)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,128 @@
+"""C-ABI surface (no compute without a GPU), host logic, and the sharded N>1 path on gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gan_segmentation_amd import _lib
+from gan_segmentation_amd import dist as gdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip_library():
+    if not os.path.exists(_lib.HIP_LIBRARY):
+        subprocess.check_call([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT)
+    return _lib.HIP_LIBRARY
+
+
+def test_header_symbols_are_exported(hip_library):
+    """Every function include/gsa.h declares is exported by the built library, and vice versa."""
+    with open(os.path.join(ROOT, "include", "gsa.h")) as f:
+        header = f.read()
+    declared = set(re.findall(r"\b(gsa_[a-z_]+)\s*\(", header)) - {"gsa_ctx"}
+    lib = ctypes.CDLL(hip_library)
+    for name in declared:
+        assert hasattr(lib, name), "%s declared in gsa.h but not exported" % name
+    assert declared == {"gsa_" + s for s in _lib.API_SYMBOLS}
+    api = _lib.Api(hip_library, "gsa_")
+    assert b"gfx950" in api.version()
+
+
+def test_product_path_fails_loudly_without_gpu(hip_library):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    api = _lib.Api(hip_library, "gsa_")
+    with pytest.raises(_lib.GsaError, match="no HIP device|device"):
+        _lib.Context(api, 0)
+    from gan_segmentation_amd import weights as W
+    from gan_segmentation_amd.networks_stylegan import Generator
+    with pytest.raises(_lib.GsaError):
+        Generator(W.reduced_generator_config(7))
+
+
+def test_missing_library_is_an_error(tmp_path):
+    with pytest.raises(_lib.GsaError, match="no CPU fallback"):
+        _lib.Api(str(tmp_path / "libnope.so"))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gan-segmentation_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                with open(os.path.join(dirpath, fn)) as f:
+                    src = f.read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+                assert "gsao_" not in src or fn == "_lib.py", fn
+
+
+def test_shard_bounds_cover_everything():
+    for total in (0, 1, 7, 8, 10000):
+        for world in (1, 2, 3, 8):
+            spans = [gdist.shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_pack_unpack_pairs():
+    import torch
+    img = torch.randint(0, 255, (3, 8, 8, 3), dtype=torch.uint8)
+    mask = torch.randint(0, 2, (3, 8, 8), dtype=torch.uint8)
+    buf = gdist.pack_pairs(img, mask)
+    assert buf.shape == (3, 8 * 8 * 4)
+    i2, m2 = gdist.unpack_pairs(buf, 8)
+    assert torch.equal(i2, img) and torch.equal(m2, mask)
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import torch.distributed as dist
+from gan_segmentation_amd import dist as gdist
+from gan_segmentation_amd import weights as W
+from oracle.binding import Oracle
+rank, world, _ = gdist.init_from_env(backend="gloo")
+gcfg = W.reduced_generator_config(5)
+gp = W.synthetic_generator_params(gcfg)
+dcfg = W.decoder_config(5, in_channels=W.generator_channels(gcfg))
+dp = W.synthetic_decoder_params(dcfg)
+total = 5                                   # ragged: ranks get 3 and 2 samples
+z, noise = W.synthetic_inputs(gcfg, total)
+lo, hi = gdist.shard_bounds(total, world, rank)
+o = Oracle(gcfg, gp, dcfg, dp)              # stands in for the HIP producer on CPU
+img, mask = o.generate(z[lo:hi], [a[lo:hi] for a in noise])
+counts = [gdist.shard_bounds(total, world, r)[1] - gdist.shard_bounds(total, world, r)[0] for r in range(world)]
+gi, gm = gdist.gather_pairs(torch.from_numpy(img), torch.from_numpy(mask), counts=counts)
+if rank == 0:
+    fi, fm = o.generate(z, noise)
+    assert gi.shape[0] == total
+    assert np.array_equal(gi.numpy(), fi) and np.array_equal(gm.numpy(), fm)
+    print("GATHER_OK")
+else:
+    assert gi is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_world_size_2_gather_on_gloo(tmp_path, oracle_lib):
+    """The N>1 path: contiguous shards + one gather reproduce the single-process result."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
+        capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "GATHER_OK" in out.stdout
