@@ -25,6 +25,31 @@ PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0
 
 
+def host_cores():
+    """Threads this process may really use: CPU affinity capped by the cgroup CPU quota; on a
+    shared GPU box that reports neither, the documented one-GPU CPU share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                quota = max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = max(1, q // p)
+        except (OSError, ValueError):
+            pass
+    if os.environ.get("GSA_CPU_THREADS"):
+        return int(os.environ["GSA_CPU_THREADS"])
+    if quota is not None:
+        return max(1, min(n, quota))
+    return n if n <= 32 else 16
+
+
 def cpu_baseline(gan, seconds_budget=25.0):
     """Stand-in for the reference's mxnet-CPU path (MXNet is not installable here): the
     semantic torch-CPU restatement (oneDNN convolutions), batch 1, all host cores."""
@@ -34,7 +59,7 @@ def cpu_baseline(gan, seconds_budget=25.0):
     mr = W.GAN_MAX_RES_LOG2[gan]
     gcfg, dcfg = W.generator_config(mr), W.decoder_config(mr)
     gp, dp = W.synthetic_generator_params(gcfg, seed=2), W.synthetic_decoder_params(dcfg, seed=3)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     times = []
     t_start = time.perf_counter()
