@@ -169,8 +169,9 @@ void free_all(std::vector<void*>& v) {
     v.clear();
 }
 
-// conv OIHW (O,I,3,3) -> [g][cb][tap][ci][n][cg]; channel = 16cb+4cg+ci, cout = g*ct+n
-std::vector<float> pack_conv3(const float* w, int O, int I, int ct, float std, bool us, float lr) {
+// conv OIHW (O,I,3,3) -> [O/16][I/16][tap][ci][16][cg]; channel = 16cb+4cg+ci, cout = 16g+n
+std::vector<float> pack_conv3(const float* w, int O, int I, float std, bool us, float lr) {
+    const int ct = 16;
     std::vector<float> out((size_t)O * I * 9);
     const int nblk = I / 16, G = O / ct;
     for (int g = 0; g < G; ++g)
@@ -186,8 +187,9 @@ std::vector<float> pack_conv3(const float* w, int O, int I, int ct, float std, b
     return out;
 }
 
-// deconv IOHW (I,O,4,4) -> [g][cb][tap16][ci][n][cg]
-std::vector<float> pack_deconv(const float* w, int I, int O, int ct, float std, bool us, float lr) {
+// deconv IOHW (I,O,4,4) -> [O/16][I/16][tap16][ci][16][cg]
+std::vector<float> pack_deconv(const float* w, int I, int O, float std, bool us, float lr) {
+    const int ct = 16;
     std::vector<float> out((size_t)O * I * 16);
     const int nblk = I / 16, G = O / ct;
     for (int g = 0; g < G; ++g)
@@ -203,8 +205,9 @@ std::vector<float> pack_deconv(const float* w, int I, int O, int ct, float std, 
     return out;
 }
 
-// 1x1 shortcut (O,I,1,1) -> [g][cb][ci][n][cg]
-std::vector<float> pack_conv1(const float* w, int O, int I, int ct) {
+// 1x1 shortcut (O,I,1,1) -> [O/16][I/16][ci][16][cg]
+std::vector<float> pack_conv1(const float* w, int O, int I) {
+    const int ct = 16;
     std::vector<float> out((size_t)O * I);
     const int nblk = I / 16, G = O / ct;
     for (int g = 0; g < G; ++g)
@@ -336,11 +339,9 @@ struct Launch {
     }
 };
 
-const char* conv_kernel_name(int H, int Cout, int epi, bool sc) {
+const char* conv_kernel_name(int H, int Cout, int n, int epi, bool sc) {
     static thread_local char buf[96];
-    const int ct = conv_cout_tile(H, Cout);
-    const int th = H >= 16 ? 16 : H;
-    snprintf(buf, sizeof buf, "conv3x3_mfma<tile%d,cout%d,%s%s>", th, ct,
+    snprintf(buf, sizeof buf, "conv3x3_mfma<%s,%s%s>", conv_geom_name(H, H, Cout, n),
              epi == EPI_RAW ? "raw" : (epi == EPI_SYNTH ? "synth" : "dec"), sc ? "+sc" : "");
     return buf;
 }
@@ -469,10 +470,10 @@ int gsa_generator_commit(gsa_ctx* c) {
             if (int rc = get_std(c, nm, &std)) return rc;
             if (B.is_deconv) {
                 NEED(P, std::string(nm) + "_weight", (size_t)Cin * C * 16, &w);
-                h = pack_deconv(w, Cin, C, deconv_cout_tile(C), std, us, 1.0f);
+                h = pack_deconv(w, Cin, C, std, us, 1.0f);
             } else {
                 NEED(P, std::string(nm) + "_weight", (size_t)Cin * C * 9, &w);
-                h = pack_conv3(w, C, Cin, conv_cout_tile(R, C), std, us, 1.0f);
+                h = pack_conv3(w, C, Cin, std, us, 1.0f);
             }
             if (int rc = upload(c, h, &B.w1, T)) return rc;
             snprintf(nm, sizeof nm, "%d_blur_1_w_kernel", R);
@@ -483,7 +484,7 @@ int gsa_generator_commit(gsa_ctx* c) {
         snprintf(nm, sizeof nm, "%d_conv_2", R);
         if (int rc = get_std(c, nm, &std)) return rc;
         NEED(P, std::string(nm) + "_weight", (size_t)C * C * 9, &w);
-        h = pack_conv3(w, C, C, conv_cout_tile(R, C), std, us, 1.0f);
+        h = pack_conv3(w, C, C, std, us, 1.0f);
         if (int rc = upload(c, h, &B.w2, T)) return rc;
         for (int k = 0; k < 2; ++k) {
             snprintf(nm, sizeof nm, "%d_noise_%d_scale_factors", R, k + 1);
@@ -598,7 +599,6 @@ int gsa_decoder_commit(gsa_ctx* c) {
     auto& T = c->d_allocs;
     for (int i = 0; i < n; ++i) {
         DecLevelDev& d = c->dl[i];
-        const int R = 4 << i;
         d.F = c->d_feat[i]; d.I = c->d_inch[i];
         d.cs = c->d_feat[i + 1];
         d.in_c = d.F * (i > 0 ? 2 : 1);
@@ -606,25 +606,25 @@ int gsa_decoder_commit(gsa_ctx* c) {
         snprintf(nm, sizeof nm, "cvt_block_%d.0", i);
         NEED(P, std::string(nm) + ".weight", (size_t)d.F * d.I * 9, &w);
         NEED(P, std::string(nm) + ".bias", (size_t)d.F, &b);
-        h = pack_conv3(w, d.F, d.I, conv_cout_tile(R, d.F), 1.0f, false, 1.0f);
+        h = pack_conv3(w, d.F, d.I, 1.0f, false, 1.0f);
         if (int rc = upload(c, h, &d.cvt_w, T)) return rc;
         h.assign(b, b + d.F);
         if (int rc = upload(c, h, &d.cvt_b, T)) return rc;
         snprintf(nm, sizeof nm, "cvt_block_%d.1", i);
         if (int rc = load_bn(c, nm, d.F, &d.cvt_s, &d.cvt_rm, &d.cvt_beta)) return rc;
         if (!d.is_last) {
-            const int second = c->d_bn ? 3 : 2, R2 = 2 * R;
+            const int second = c->d_bn ? 3 : 2;
             const std::string pf = "main_block_" + std::to_string(i) + ".1.base_layers";
             NEED(P, pf + ".0.weight", (size_t)d.cs * d.in_c * 9, &w);
             NEED(P, pf + ".0.bias", (size_t)d.cs, &b);
-            h = pack_conv3(w, d.cs, d.in_c, conv_cout_tile(R2, d.cs), 1.0f, false, 1.0f);
+            h = pack_conv3(w, d.cs, d.in_c, 1.0f, false, 1.0f);
             if (int rc = upload(c, h, &d.a_w, T)) return rc;
             h.assign(b, b + d.cs);
             if (int rc = upload(c, h, &d.a_b, T)) return rc;
             if (int rc = load_bn(c, pf + ".1", d.cs, &d.a_s, &d.a_rm, &d.a_beta)) return rc;
             NEED(P, pf + "." + std::to_string(second) + ".weight", (size_t)d.cs * d.cs * 9, &w);
             NEED(P, pf + "." + std::to_string(second) + ".bias", (size_t)d.cs, &b);
-            h = pack_conv3(w, d.cs, d.cs, conv_cout_tile(R2, d.cs), 1.0f, false, 1.0f);
+            h = pack_conv3(w, d.cs, d.cs, 1.0f, false, 1.0f);
             if (int rc = upload(c, h, &d.b_w, T)) return rc;
             h.assign(b, b + d.cs);
             if (int rc = upload(c, h, &d.b_b, T)) return rc;
@@ -634,7 +634,7 @@ int gsa_decoder_commit(gsa_ctx* c) {
                 const std::string sc = "main_block_" + std::to_string(i) + ".1.shortcut.0";
                 NEED(P, sc + ".weight", (size_t)d.cs * d.in_c, &w);
                 NEED(P, sc + ".bias", (size_t)d.cs, &b);
-                h = pack_conv1(w, d.cs, d.in_c, conv_cout_tile(R2, d.cs));
+                h = pack_conv1(w, d.cs, d.in_c);
                 if (int rc = upload(c, h, &d.sc_w, T)) return rc;
                 h.assign(b, b + d.cs);
                 if (int rc = upload(c, h, &d.sc_b, T)) return rc;
@@ -681,7 +681,8 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
             maxC = std::max(maxC, c->ch[l]);
             if (int rc = dev_alloc(c, N * R * R * C, &c->x2[l], T)) return rc;
             if (int rc = dev_alloc(c, N * C, &c->aff2[l], T)) return rc;
-            prow_elems = std::max(prow_elems, (size_t)conv_stat_rows((int)R, (int)R, (int)C) * C);
+            for (int nb = 1; nb <= max_batch; ++nb)
+                prow_elems = std::max(prow_elems, (size_t)conv_stat_rows((int)R, (int)R, (int)C, nb) * C);
             prow_elems = std::max(prow_elems, (size_t)post_prow((int)R, (int)R, (int)C) * C);
         }
         if (int rc = dev_alloc(c, N * maxact, &c->t_raw, T)) return rc;
@@ -751,13 +752,13 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                     if (B.is_deconv) {
                         snprintf(layer, sizeof layer, "g.%d.deconv_1", R);
                         static thread_local char kn[64];
-                        snprintf(kn, sizeof kn, "deconv4x4_mfma<cout%d>", deconv_cout_tile(C));
+                        snprintf(kn, sizeof kn, "deconv4x4_mfma<%s>", deconv_geom_name(C));
                         Launch lp(c, s, kn, layer, 2.0 * px * C * Cin * 4, 4.0 * (px / 4 * Cin + px * C));
                         HIP_TRY(launch_deconv4x4(cp, n, s));
                     } else {
                         cp.up = 1;
                         snprintf(layer, sizeof layer, "g.%d.conv_1", R);
-                        Launch lp(c, s, conv_kernel_name(R, C, EPI_RAW, false), layer, 2.0 * px * C * Cin * 9, 4.0 * (px / 4 * Cin + px * C));
+                        Launch lp(c, s, conv_kernel_name(R, C, n, EPI_RAW, false), layer, 2.0 * px * C * Cin * 9, 4.0 * (px / 4 * Cin + px * C));
                         HIP_TRY(launch_conv3x3(cp, EPI_RAW, false, n, s));
                     }
                     pp.src = c->t_raw; pp.src_per_sample = 1; pp.blur = B.blur;
@@ -773,9 +774,9 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 cp.wpk = B.w2; cp.Cout = C; cp.out = c->x2[l];
                 cp.noise = nz; cp.nscale = B.nscale[1]; cp.nbias = B.nbias[1]; cp.partials = c->partials;
                 snprintf(layer, sizeof layer, "g.%d.conv_2", R);
-                Launch lp(c, s, conv_kernel_name(R, C, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
+                Launch lp(c, s, conv_kernel_name(R, C, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
-                prow = conv_stat_rows(R, R, C);
+                prow = conv_stat_rows(R, R, C, n);
             }
             FinalizeParams fp{};
             fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C; fp.acc = c->stat_acc;
@@ -818,7 +819,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             cp.wpk = d.cvt_w; cp.Cout = d.F; cp.out = c->cvt[i];
             cp.bias = d.cvt_b; cp.bn_s = d.cvt_s; cp.bn_rm = d.cvt_rm; cp.bn_beta = d.cvt_beta;
             snprintf(layer, sizeof layer, "d.cvt_%d", i);
-            Launch lp(c, s, conv_kernel_name(R, d.F, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
+            Launch lp(c, s, conv_kernel_name(R, d.F, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
             HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
         }
         if (!d.is_last) {
@@ -833,7 +834,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 cp.bias = d.a_b; cp.bn_s = d.a_s; cp.bn_rm = d.a_rm; cp.bn_beta = d.a_beta;
                 if (d.has_sc) { cp.wsc = d.sc_w; cp.sc_bias = d.sc_b; cp.out_sc = c->scb[i]; }
                 snprintf(layer, sizeof layer, "d.main_%d.a", i);
-                Launch lp(c, s, conv_kernel_name(R2, d.cs, EPI_DEC, d.has_sc), layer,
+                Launch lp(c, s, conv_kernel_name(R2, d.cs, n, EPI_DEC, d.has_sc), layer,
                           2.0 * px2 * d.cs * d.in_c * (9 + (d.has_sc ? 1 : 0)), 4.0 * (px * d.in_c + px2 * d.cs * (d.has_sc ? 2 : 1)));
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, d.has_sc, n, s));
             }
@@ -846,7 +847,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = 0; }
                 else { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
-                Launch lp(c, s, conv_kernel_name(R2, d.cs, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
+                Launch lp(c, s, conv_kernel_name(R2, d.cs, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
             }
         } else {

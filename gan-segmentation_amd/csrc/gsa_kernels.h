@@ -25,7 +25,7 @@ struct ConvParams {
     int Hs, Ws;      // spatial size of the sources
     int up;          // 1: logical input is the nearest x2 upsample of the sources
     int H, W;        // output size
-    const float* wpk;   // packed weights [cout group][c16][tap][ci][n][cg]
+    const float* wpk;   // packed weights [Cout/16][Cin/16][tap][ci][16][cg]
     int Cout;           // total output channels
     float* out;         // NHWC
     // EPI_SYNTH: AddNoise -> Bias -> LeakyReLU -> statistics
@@ -74,10 +74,10 @@ hipError_t launch_final_conv(const float* src0, int C0, const float* src1, int C
                              const float* bias, float* logits, uint8_t* mask, int n, int H, int W, int ncls,
                              hipStream_t s);
 
-// packing geometry shared with the host-side weight packer
-int conv_cout_tile(int H, int Cout);          // output channels per workgroup of conv3x3 at output size H
-int deconv_cout_tile(int Cout);               // ... of deconv4x4
-int conv_stat_rows(int H, int W, int Cout);   // statistic partial rows per sample written by conv3x3 EPI_SYNTH
-int post_prow(int H, int W, int C);           // ... written by the post kernel
+// geometry the launchers pick (weights are packed per 16 output channels, so it is free to vary)
+int conv_stat_rows(int H, int W, int Cout, int n);   // statistic partial rows per sample written by conv3x3 EPI_SYNTH
+int post_prow(int H, int W, int C);                  // ... written by the post kernel
+const char* conv_geom_name(int H, int W, int Cout, int n);   // "tile16,cout64" -- for profile labels
+const char* deconv_geom_name(int Cout);
 
 }  // namespace gsa

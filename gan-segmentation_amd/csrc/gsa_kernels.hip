@@ -22,6 +22,8 @@
 //   final_conv      final Conv2D + argmax               networks_seg.py:91-92; seg_solver.py:326
 #include "gsa_kernels.h"
 
+#include <cstdio>
+
 namespace gsa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -43,26 +45,78 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 }
 
 // ------------------------------------------------------------------------------------------
-// conv3x3 (pad 1) as implicit GEMM on v_mfma_f32_16x16x4_f32.
+// Shared pieces of the two MFMA convolutions.
 //
+// LDS image of an input tile (1-pixel halo): [row][pixel][16 channels]; the 16 channels of a
+// block are stored transposed 4x4 (position ci*4+cg holds channel 4*cg+ci) so ONE ds_read_b128
+// per lane yields the A operands of 4 consecutive MFMAs (lane = (pixel i, k slot ci)).  A row
+// stride = 8 (mod 16) floats makes those reads bank-conflict free.  Weights are packed in HBM
+// per (16 output channels, 16-channel block) as [tap][ci][n][cg] and copied verbatim.
+//
+// Staging is split (load to registers early / write to LDS late) so that the global loads of
+// block cb+1 are in flight while the MFMAs of block cb run.
+
+struct TilePixel {   // one staged pixel of this thread
+    int pix;         // pixel index into the source tensors ((n*Hs+sy)*Ws+sx), or -1: zero padding
+    int lds;         // float offset in the LDS image, or -1: this thread stages nothing
+};
+
+// Unconditional loads (padding / idle threads read pixel 0 and discard it): no branch sits
+// between a global load and its use, so the compiler keeps every load of a block in flight.
+__device__ __forceinline__ void load_pixel(f32x4 (&v)[4], const float* src, int Cs, int coff, const TilePixel& tp) {
+    const int pix = tp.pix >= 0 ? tp.pix : 0;
+    const f32x4* ptr = reinterpret_cast<const f32x4*>(src + (size_t)pix * Cs + coff);
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) v[cg] = ptr[cg];
+}
+
+// AdaIN on the fly (zero padding stays zero), then the transposed 4x4 store.
+// HAS_AFF is wave-uniform; the coefficients of the sample were copied to LDS (saff, one float4
+// per input channel) at kernel start, so the write phase issues no global load.
+template <bool HAS_AFF>
+__device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const float4* saff, const TilePixel& tp) {
+    const bool inside = tp.pix >= 0;
+    float f[16] = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3],
+                   v[2][0], v[2][1], v[2][2], v[2][3], v[3][0], v[3][1], v[3][2], v[3][3]};
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float t = f[c];
+        if (HAS_AFF) {
+            const float4 a = saff[c];    // (mean, A, B, -)
+            t = fmaf(t - a.x, a.y, a.z);
+        }
+        f[c] = inside ? t : 0.0f;
+    }
+    if (tp.lds >= 0) {
+        f32x4* dst = reinterpret_cast<f32x4*>(sA + tp.lds);
+        dst[0] = f32x4{f[0], f[4], f[8], f[12]};
+        dst[1] = f32x4{f[1], f[5], f[9], f[13]};
+        dst[2] = f32x4{f[2], f[6], f[10], f[14]};
+        dst[3] = f32x4{f[3], f[7], f[11], f[15]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv3x3 (pad 1) as implicit GEMM on v_mfma_f32_16x16x4_f32.
 // Workgroup = WM*WN waves, output tile TH x TW pixels x COUT_T = 16*NT*WN channels.
-// LDS image of the input tile (with 1-pixel halo): [row][pixel][16 channels], the 16 channels
-// of a block stored transposed 4x4 (position ci*4+cg holds channel 4*cg+ci) so that one
-// ds_read_b128 per lane yields the A operands of 4 consecutive MFMAs; row stride = 8 mod 16
-// floats makes those reads bank-conflict free.  Weights of the block are staged as
-// [tap][ci][n][cg], read the same way.
 template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
     constexpr int NW = WM * WN, NTHR = 64 * NW;
     constexpr int PW = TW / 4, MT = (TH / 4) * PW / WM;
     constexpr int LH = TH + 2, LW = TW + 2;
     constexpr int RS = LW * 16 + 8;              // floats; RS % 16 == 8
-    constexpr int COUT_T = 16 * NT * WN;
-    constexpr int NB = 9 * 16 * COUT_T;          // weight floats per 16-channel block
+    constexpr int Q = NT * WN;                   // 16-channel output groups per workgroup
+    constexpr int COUT_T = 16 * Q;
+    constexpr int SEG = 9 * 256;                 // weight floats per (16 couts, 16-channel block)
+    constexpr int NB4 = Q * SEG / 4;             // float4s of weights per block
+    constexpr int AIT = (LH * LW + NTHR - 1) / NTHR;
+    constexpr int BIT = (NB4 + NTHR - 1) / NTHR;
+    constexpr int SIT = (Q * 64 + NTHR - 1) / NTHR;   // shortcut weights: Q*256 floats
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
-    float* sB = sA + LH * RS;
-    float* sS = sB + NB;                         // SC: [ci][n][cg]
+    float* sB = sA + LH * RS;                    // [q][tap][ci][16][cg]
+    float* sS = sB + Q * SEG;                    // SC: [q][ci][16][cg]
+    float4* sAff = reinterpret_cast<float4*>(sS + (SC ? Q * 256 : 0));   // [C0] (mean, A, B, -)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,13 +126,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
     const int g = blockIdx.y, n = blockIdx.z;
     const int i16 = lane & 15, kq = lane >> 4;
 
+    TilePixel tp[AIT];
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+        const int idx = tid + it * NTHR;
+        tp[it].pix = -1; tp[it].lds = -1;
+        if (idx < LH * LW) {
+            const int ly = idx / LW, lx = idx % LW;
+            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+            tp[it].lds = ly * RS + lx * 16;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) tp[it].pix = (n * p.Hs + (gy >> p.up)) * p.Ws + (gx >> p.up);
+        }
+    }
     int abase[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
         abase[mt] = (pr * 4 + (i16 >> 2)) * RS + (pc * 4 + (i16 & 3)) * 16 + kq * 4;
     }
-    const int bbase = (kq * COUT_T + wn * NT * 16 + i16) * 4;
+    const int bbase = wn * NT * SEG + (kq * 16 + i16) * 4;
+    const int sbase = wn * NT * 256 + (kq * 16 + i16) * 4;
 
     f32x4 acc[MT][NT];
     f32x4 accs[SC ? MT : 1][SC ? NT : 1];
@@ -91,54 +158,57 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         }
 
     const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4;
-    for (int cb = 0; cb < nblk; ++cb) {
+    f32x4 ra[AIT][4], rb[BIT], rs[SC ? SIT : 1];
+
+    auto load_block = [&](int cb) {
         const bool first = cb < nblk0;
         const float* src = first ? p.src0 : p.src1;
         const int Cs = first ? p.C0 : p.C1;
         const int coff = (first ? cb : cb - nblk0) * 16;
-        const Aff* aff = (first && p.aff0) ? p.aff0 + (size_t)n * p.C0 + coff : nullptr;
-        // ---- stage the input tile (AdaIN applied on the fly, zero padding after it)
-        for (int idx = tid; idx < LH * LW; idx += NTHR) {
-            const int ly = idx / LW, lx = idx % LW;
-            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
-            float4 v[4];
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                const float4* ptr = reinterpret_cast<const float4*>(
-                    src + ((size_t)(n * p.Hs + (gy >> p.up)) * p.Ws + (gx >> p.up)) * Cs + coff);
 #pragma unroll
-                for (int cg = 0; cg < 4; ++cg) v[cg] = ptr[cg];
-                if (aff) {
+        for (int it = 0; it < AIT; ++it) load_pixel(ra[it], src, Cs, coff, tp[it]);
 #pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) {
-                        const Aff a0 = aff[cg * 4 + 0], a1 = aff[cg * 4 + 1], a2 = aff[cg * 4 + 2], a3 = aff[cg * 4 + 3];
-                        v[cg].x = fmaf(v[cg].x - a0.mean, a0.A, a0.B);
-                        v[cg].y = fmaf(v[cg].y - a1.mean, a1.A, a1.B);
-                        v[cg].z = fmaf(v[cg].z - a2.mean, a2.A, a2.B);
-                        v[cg].w = fmaf(v[cg].w - a3.mean, a3.A, a3.B);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int cg = 0; cg < 4; ++cg) v[cg] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            float4* dst = reinterpret_cast<float4*>(sA + ly * RS + lx * 16);
-            dst[0] = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-            dst[1] = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-            dst[2] = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
-            dst[3] = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+        for (int j = 0; j < BIT; ++j) {
+            const int i = min(tid + j * NTHR, NB4 - 1);    // clamped: duplicates rewrite the same value
+            const int q = i / (SEG / 4), r = i % (SEG / 4);
+            rb[j] = reinterpret_cast<const f32x4*>(p.wpk + ((size_t)(g * Q + q) * nblk + cb) * SEG)[r];
         }
-        // ---- stage the weights of this block (already in LDS order in HBM)
-        {
-            const float4* wsrc = reinterpret_cast<const float4*>(p.wpk + ((size_t)g * nblk + cb) * NB);
-            float4* wdst = reinterpret_cast<float4*>(sB);
-            for (int idx = tid; idx < NB / 4; idx += NTHR) wdst[idx] = wsrc[idx];
-            if (SC) {
-                const float4* ssrc = reinterpret_cast<const float4*>(p.wsc + ((size_t)g * nblk + cb) * (16 * COUT_T));
-                float4* sdst = reinterpret_cast<float4*>(sS);
-                for (int idx = tid; idx < 16 * COUT_T / 4; idx += NTHR) sdst[idx] = ssrc[idx];
+        if (SC) {
+#pragma unroll
+            for (int j = 0; j < SIT; ++j) {
+                const int i = min(tid + j * NTHR, Q * 64 - 1);
+                const int q = i / 64, r = i % 64;
+                rs[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)(g * Q + q) * nblk + cb) * 256)[r];
             }
         }
+    };
+    auto write_block = [&](int cb) {
+        if (cb < nblk0 && p.aff0) {      // wave-uniform
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) store_pixel<true>(sA, ra[it], sAff + cb * 16, tp[it]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) store_pixel<false>(sA, ra[it], sAff, tp[it]);
+        }
+#pragma unroll
+        for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB)[min(tid + j * NTHR, NB4 - 1)] = rb[j];
+        if (SC) {
+#pragma unroll
+            for (int j = 0; j < SIT; ++j) reinterpret_cast<f32x4*>(sS)[min(tid + j * NTHR, Q * 64 - 1)] = rs[j];
+        }
+    };
+
+    load_block(0);
+    if (p.aff0) {
+        const float4* ga = reinterpret_cast<const float4*>(p.aff0 + (size_t)n * p.C0);
+        for (int i = tid; i < p.C0; i += NTHR) sAff[i] = ga[i];
         __syncthreads();
+    }
+    write_block(0);
+    __syncthreads();
+    for (int cb = 0; cb < nblk; ++cb) {
+        load_block(min(cb + 1, nblk - 1));         // in flight during the MFMAs below (the last one is a harmless reload)
+        __builtin_amdgcn_sched_barrier(0);         // keep the consumers of those loads below the MFMAs
         // ---- MFMA: K order (tap, cg, ci) inside the block
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -147,8 +217,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(sA + abase[mt] + toff);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                b[nt] = *reinterpret_cast<const f32x4*>(sB + tap * 16 * COUT_T + bbase + nt * 64);
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(sB + bbase + nt * SEG + tap * 256);
 #pragma unroll
             for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
@@ -159,7 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
             if (SC && tap == 4) {  // 1x1 shortcut on the centre tap, natural channel order
                 f32x4 bs[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bs[nt] = *reinterpret_cast<const f32x4*>(sS + bbase + nt * 64);
+                for (int nt = 0; nt < NT; ++nt) bs[nt] = *reinterpret_cast<const f32x4*>(sS + sbase + nt * 256);
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
@@ -169,32 +238,69 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
                             accs[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], bs[nt][cg], accs[mt][nt], 0, 0, 0);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (cb + 1 < nblk) {
+            __syncthreads();          // every wave has finished reading this block
+            write_block(cb + 1);
+            __syncthreads();
+        }
     }
 
-    // ---- epilogue.  C layout: lane -> (channel = lane&15, patch row = lane>>4), reg -> patch column
+    // ---- epilogue.  C layout: lane -> (channel = lane&15, patch row = lane>>4), reg -> patch column.
+    // Every global load (noise, residual, per-channel constants) is issued before the first
+    // store: the compiler cannot move a load above a store that might alias it.
     const int prow_in_patch = lane >> 4;
+    size_t pixs[MT];
+    float4 nzs[EPI == EPI_SYNTH ? MT : 1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
+        const int y = y0 + pr * 4 + prow_in_patch, x = x0 + pc * 4;
+        pixs[mt] = (size_t)(n * p.H + y) * p.W + x;
+        if (EPI == EPI_SYNTH) nzs[mt] = *reinterpret_cast<const float4*>(p.noise + pixs[mt]);
+    }
+    float e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = g * COUT_T + wn * NT * 16 + nt * 16 + i16;
-        unsigned long long I1 = 0, I2 = 0;
-        float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, scb = 0.f;
-        if (EPI == EPI_SYNTH) { e0 = p.nscale[co]; e1 = p.nbias[co]; }
-        if (EPI == EPI_DEC) { e0 = p.bias[co]; e1 = p.bn_rm[co]; e2 = p.bn_s[co]; e3 = p.bn_beta[co]; }
-        if (SC) scb = p.sc_bias[co];
+        const int co = g * COUT_T + (wn * NT + nt) * 16 + i16;
+        e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = 0.f;
+        if (EPI == EPI_SYNTH) { e0[nt] = p.nscale[co]; e1[nt] = p.nbias[co]; }
+        if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
+        if (SC) scb[nt] = p.sc_bias[co];
+    }
+    float rr[EPI == EPI_DEC ? MT : 1][EPI == EPI_DEC ? NT : 1][4];
+    const bool has_resid = EPI == EPI_DEC && p.resid != nullptr;
+    if (EPI == EPI_DEC && has_resid) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
             const int y = y0 + pr * 4 + prow_in_patch, x = x0 + pc * 4;
-            const size_t pix = (size_t)(n * p.H + y) * p.W + x;
-            float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
-            if (EPI == EPI_SYNTH) {
-                const float4 nz = *reinterpret_cast<const float4*>(p.noise + pix);
-                const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = g * COUT_T + (wn * NT + nt) * 16 + i16;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float t = e0 * nzv[r];
-                    v[r] = lrelu((v[r] + t) + e1);
+                    const size_t rp = p.resid_up ? (size_t)(n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + ((x + r) >> 1)
+                                                 : pixs[mt] + r;
+                    rr[mt][nt][r] = p.resid[rp * p.Cout + co];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = g * COUT_T + (wn * NT + nt) * 16 + i16;
+        unsigned long long I1 = 0, I2 = 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const size_t pix = pixs[mt];
+            float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+            if (EPI == EPI_SYNTH) {
+                const float nzv[4] = {nzs[mt].x, nzs[mt].y, nzs[mt].z, nzs[mt].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = e0[nt] * nzv[r];
+                    v[r] = lrelu((v[r] + t) + e1[nt]);
                 }
                 const float s = (v[0] + v[1]) + (v[2] + v[3]);
                 const float q = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
@@ -204,21 +310,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
             if (EPI == EPI_DEC) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float yv = v[r] + e0;
-                    v[r] = lrelu(fmaf(yv - e1, e2, e3));
-                    if (p.resid) {
-                        const size_t rp = p.resid_up
-                                              ? (size_t)(n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + ((x + r) >> 1)
-                                              : pix + r;
-                        v[r] = p.resid[rp * p.Cout + co] + v[r];
-                    }
+                    const float yv = v[r] + e0[nt];
+                    v[r] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
+                    if (has_resid) v[r] = rr[mt][nt][r] + v[r];
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) p.out[(pix + r) * p.Cout + co] = v[r];
             if (SC) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p.out_sc[(pix + r) * p.Cout + co] = accs[mt][nt][r] + scb;
+                for (int r = 0; r < 4; ++r) p.out_sc[(pix + r) * p.Cout + co] = accs[mt][nt][r] + scb[nt];
             }
         }
         if (EPI == EPI_SYNTH) {
@@ -239,10 +340,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
 template <int NT>
 __global__ __launch_bounds__(256) void deconv4x4_mfma(ConvParams p) {
     constexpr int LH = 10, LW = 10, RS = LW * 16 + 8;
-    constexpr int COUT_T = 16 * NT, NB = 16 * 16 * COUT_T;
+    constexpr int COUT_T = 16 * NT, SEG = 16 * 256, NB4 = NT * SEG / 4, BIT = (NB4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
-    float* sB = sA + LH * RS;
+    float* sB = sA + LH * RS;                     // [q][tap16][ci][16][cg]
+    float4* sAff = reinterpret_cast<float4*>(sB + NT * SEG);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int py = wave >> 1, px = wave & 1;
@@ -251,11 +353,19 @@ __global__ __launch_bounds__(256) void deconv4x4_mfma(ConvParams p) {
     const int iy0 = y0 / 2 - 1, ix0 = x0 / 2 - 1;   // input tile origin (with halo)
     const int g = blockIdx.y, n = blockIdx.z;
     const int i16 = lane & 15, kq = lane >> 4;
+    TilePixel tp;
+    tp.pix = -1; tp.lds = -1;
+    if (tid < LH * LW) {
+        const int ly = tid / LW, lx = tid % LW;
+        const int gy = iy0 + ly, gx = ix0 + lx;
+        tp.lds = ly * RS + lx * 16;
+        if (gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws) tp.pix = (n * p.Hs + gy) * p.Ws + gx;
+    }
     int abase[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
         abase[mt] = ((mt >> 1) * 4 + (i16 >> 2) + 1) * RS + ((mt & 1) * 4 + (i16 & 3) + 1) * 16 + kq * 4;
-    const int bbase = (kq * COUT_T + i16) * 4;
+    const int bbase = (kq * 16 + i16) * 4;
     f32x4 acc[4][NT];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -263,43 +373,33 @@ __global__ __launch_bounds__(256) void deconv4x4_mfma(ConvParams p) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nblk = p.C0 >> 4;
-    for (int cb = 0; cb < nblk; ++cb) {
-        const Aff* aff = p.aff0 ? p.aff0 + (size_t)n * p.C0 + cb * 16 : nullptr;
-        for (int idx = tid; idx < LH * LW; idx += 256) {
-            const int ly = idx / LW, lx = idx % LW;
-            const int gy = iy0 + ly, gx = ix0 + lx;
-            float4 v[4];
-            if (gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws) {
-                const float4* ptr = reinterpret_cast<const float4*>(
-                    p.src0 + ((size_t)(n * p.Hs + gy) * p.Ws + gx) * p.C0 + cb * 16);
+    f32x4 ra[4], rb[BIT];
+    auto load_block = [&](int cb) {
+        load_pixel(ra, p.src0, p.C0, cb * 16, tp);
 #pragma unroll
-                for (int cg = 0; cg < 4; ++cg) v[cg] = ptr[cg];
-                if (aff) {
-#pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) {
-                        const Aff a0 = aff[cg * 4 + 0], a1 = aff[cg * 4 + 1], a2 = aff[cg * 4 + 2], a3 = aff[cg * 4 + 3];
-                        v[cg].x = fmaf(v[cg].x - a0.mean, a0.A, a0.B);
-                        v[cg].y = fmaf(v[cg].y - a1.mean, a1.A, a1.B);
-                        v[cg].z = fmaf(v[cg].z - a2.mean, a2.A, a2.B);
-                        v[cg].w = fmaf(v[cg].w - a3.mean, a3.A, a3.B);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int cg = 0; cg < 4; ++cg) v[cg] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            float4* dst = reinterpret_cast<float4*>(sA + ly * RS + lx * 16);
-            dst[0] = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-            dst[1] = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-            dst[2] = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
-            dst[3] = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+        for (int j = 0; j < BIT; ++j) {
+            const int i = min(tid + j * 256, NB4 - 1);
+            const int q = i / (SEG / 4), r = i % (SEG / 4);
+            rb[j] = reinterpret_cast<const f32x4*>(p.wpk + ((size_t)(g * NT + q) * nblk + cb) * SEG)[r];
         }
-        {
-            const float4* wsrc = reinterpret_cast<const float4*>(p.wpk + ((size_t)g * nblk + cb) * NB);
-            float4* wdst = reinterpret_cast<float4*>(sB);
-            for (int idx = tid; idx < NB / 4; idx += 256) wdst[idx] = wsrc[idx];
-        }
+    };
+    auto write_block = [&](int cb) {
+        if (p.aff0) store_pixel<true>(sA, ra, sAff + cb * 16, tp);
+        else store_pixel<false>(sA, ra, sAff, tp);
+#pragma unroll
+        for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB)[min(tid + j * 256, NB4 - 1)] = rb[j];
+    };
+    load_block(0);
+    if (p.aff0) {
+        const float4* ga = reinterpret_cast<const float4*>(p.aff0 + (size_t)n * p.C0);
+        for (int i = tid; i < p.C0; i += 256) sAff[i] = ga[i];
         __syncthreads();
+    }
+    write_block(0);
+    __syncthreads();
+    for (int cb = 0; cb < nblk; ++cb) {
+        load_block(min(cb + 1, nblk - 1));
+        __builtin_amdgcn_sched_barrier(0);
         // valid taps of this parity class, ascending ky then kx:
         //   py==0: ky=1 (dy 0), ky=3 (dy -1);   py==1: ky=0 (dy +1), ky=2 (dy 0)
 #pragma unroll
@@ -316,8 +416,7 @@ __global__ __launch_bounds__(256) void deconv4x4_mfma(ConvParams p) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(sA + abase[mt] + toff);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    b[nt] = *reinterpret_cast<const f32x4*>(sB + tap * 16 * COUT_T + bbase + nt * 64);
+                for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(sB + bbase + nt * SEG + tap * 256);
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
@@ -327,7 +426,12 @@ __global__ __launch_bounds__(256) void deconv4x4_mfma(ConvParams p) {
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (cb + 1 < nblk) {
+            __syncthreads();
+            write_block(cb + 1);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -691,34 +795,59 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* src0, int 
 // ========================================================================================
 // host-side launchers
 
-int conv_cout_tile(int H, int Cout) {
-    if (H == 4) return Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16));
-    if (H == 8) return Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16);
-    return Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16);
+// ---- conv3x3 geometry selection --------------------------------------------------------
+// Candidates per output size, most efficient first; the first one that fills the chip
+// (>= 2 workgroups per CU) wins, otherwise the one with the most workgroups.
+struct ConvGeom { int th, wm, wn, nt; };
+static const ConvGeom kGeom4[] = {{4, 1, 4, 1}, {4, 1, 2, 1}, {4, 1, 1, 1}};
+static const ConvGeom kGeom8[] = {{8, 4, 1, 4}, {8, 4, 1, 2}, {8, 4, 1, 1}};
+static const ConvGeom kGeom16[] = {{16, 4, 1, 4}, {16, 4, 1, 2}, {16, 4, 1, 1}, {8, 4, 1, 4}, {8, 4, 1, 2}, {8, 4, 1, 1}};
+
+static ConvGeom pick_geom(int H, int W, int Cout, int n) {
+    const ConvGeom* cand = H == 4 ? kGeom4 : (H == 8 ? kGeom8 : kGeom16);
+    const int ncand = H == 4 ? 3 : (H == 8 ? 3 : 6);
+    ConvGeom best = cand[ncand - 1];
+    long best_wgs = -1;
+    for (int i = 0; i < ncand; ++i) {
+        const ConvGeom& c = cand[i];
+        const int ct = 16 * c.nt * c.wn;
+        if (Cout % ct) continue;
+        const long wgs = (long)(H / c.th) * (W / c.th) * (Cout / ct) * n;
+        if (wgs >= 512) return c;
+        if (wgs > best_wgs) { best_wgs = wgs; best = c; }
+    }
+    return best;
 }
 
-static int conv_wm(int H, int Cout) {
-    if (H == 4) return 1;
-    if (H == 8) return conv_cout_tile(H, Cout) == 16 ? 4 : 2;
-    return 4;
+int conv_stat_rows(int H, int W, int Cout, int n) {
+    const ConvGeom c = pick_geom(H, W, Cout, n);
+    return (H / c.th) * (W / c.th) * c.wm;
 }
 
 int post_prow(int H, int W, int C) { return (H * (W / 4) * (C / 4) + 255) / 256; }
 
+const char* conv_geom_name(int H, int W, int Cout, int n) {
+    static thread_local char buf[48];
+    const ConvGeom c = pick_geom(H, W, Cout, n);
+    snprintf(buf, sizeof buf, "tile%d,cout%d", c.th, 16 * c.nt * c.wn);
+    return buf;
+}
+
 template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC>
 static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
-    constexpr int COUT_T = 16 * NT * WN;
+    constexpr int Q = NT * WN, COUT_T = 16 * Q;
     constexpr int RS = (TW + 2) * 16 + 8;
-    constexpr size_t lds = sizeof(float) * ((TH + 2) * RS + 9 * 16 * COUT_T + (SC ? 16 * COUT_T : 0));
+    const size_t lds = sizeof(float) * ((TH + 2) * RS + Q * 9 * 256 + (SC ? Q * 256 : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
     auto kern = conv3x3_mfma<TH, TW, WM, WN, NT, EPI, SC>;
     static bool attr_done = false;
-    if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     ConvParams q = p;
     q.tiles_x = p.W / TW;
+    q.prow = (p.H / TH) * (p.W / TW) * WM;
     dim3 grid((p.H / TH) * (p.W / TW), p.Cout / COUT_T, n);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, q);
     return hipGetLastError();
@@ -738,41 +867,26 @@ static hipError_t launch_conv_e(const ConvParams& p, int epi, bool sc, int n, hi
     return hipErrorInvalidValue;
 }
 
-// statistic partial rows written per sample for this layer geometry (tiles * WM)
-int conv_stat_rows(int H, int W, int Cout) {
-    const int th = H >= 16 ? 16 : H;
-    return (H / th) * (W / th) * conv_wm(H, Cout);
-}
-
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     if (p.H != p.W || (p.H & (p.H - 1)) || p.H < 4 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
-    ConvParams q = p;
-    q.prow = conv_stat_rows(p.H, p.W, p.Cout);
-    const int ct = conv_cout_tile(p.H, p.Cout);
-    if (p.H == 4) {
-        if (ct == 128) return launch_conv_e<4, 4, 1, 4, 2>(q, epi, sc, n, s);
-        if (ct == 64) return launch_conv_e<4, 4, 1, 4, 1>(q, epi, sc, n, s);
-        if (ct == 32) return launch_conv_e<4, 4, 1, 2, 1>(q, epi, sc, n, s);
-        return launch_conv_e<4, 4, 1, 1, 1>(q, epi, sc, n, s);
-    }
-    if (p.H == 8) {
-        if (ct == 64) return launch_conv_e<8, 8, 2, 2, 2>(q, epi, sc, n, s);
-        if (ct == 32) return launch_conv_e<8, 8, 2, 2, 1>(q, epi, sc, n, s);
-        return launch_conv_e<8, 8, 4, 1, 1>(q, epi, sc, n, s);
-    }
-    if (ct == 64) return launch_conv_e<16, 16, 4, 1, 4>(q, epi, sc, n, s);
-    if (ct == 32) return launch_conv_e<16, 16, 4, 1, 2>(q, epi, sc, n, s);
-    return launch_conv_e<16, 16, 4, 1, 1>(q, epi, sc, n, s);
+    const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
+#define GSA_GEOM(TH, WM, WN, NT) \
+    if (c.th == TH && c.wm == WM && c.wn == WN && c.nt == NT) return launch_conv_e<TH, TH, WM, WN, NT>(p, epi, sc, n, s);
+    GSA_GEOM(4, 1, 4, 1) GSA_GEOM(4, 1, 2, 1) GSA_GEOM(4, 1, 1, 1)
+    GSA_GEOM(8, 4, 1, 4) GSA_GEOM(8, 4, 1, 2) GSA_GEOM(8, 4, 1, 1)
+    GSA_GEOM(16, 4, 1, 4) GSA_GEOM(16, 4, 1, 2) GSA_GEOM(16, 4, 1, 1)
+#undef GSA_GEOM
+    return hipErrorInvalidValue;
 }
 
 template <int NT>
 static hipError_t launch_deconv_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int COUT_T = 16 * NT;
-    constexpr size_t lds = sizeof(float) * (10 * (10 * 16 + 8) + 16 * 16 * COUT_T);
+    const size_t lds = sizeof(float) * (10 * (10 * 16 + 8) + NT * 16 * 256) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
     auto kern = deconv4x4_mfma<NT>;
     static bool attr_done = false;
-    if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
@@ -783,7 +897,13 @@ static hipError_t launch_deconv_t(const ConvParams& p, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
-int deconv_cout_tile(int Cout) { return Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16); }
+static int deconv_cout_tile(int Cout) { return Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16); }
+
+const char* deconv_geom_name(int Cout) {
+    static thread_local char buf[32];
+    snprintf(buf, sizeof buf, "cout%d", deconv_cout_tile(Cout));
+    return buf;
+}
 
 hipError_t launch_deconv4x4(const ConvParams& p, int n, hipStream_t s) {
     if (p.H != 2 * p.Hs || p.W != 2 * p.Ws || p.H % 16 || p.W % 16 || p.Cout % 16 || p.C0 % 16 || p.C1) return hipErrorInvalidValue;
