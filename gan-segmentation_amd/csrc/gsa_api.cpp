@@ -105,6 +105,7 @@ struct gsa_ctx {
     Aff* aff2[kMaxLevels] = {nullptr};
     StatPart* partials = nullptr;
     StatPart* stat_acc = nullptr;
+    unsigned long long* stamps = nullptr;   // diagnostic build only
     float* din[kMaxLevels] = {nullptr};
     float* cvt[kMaxLevels] = {nullptr};
     float *ya[kMaxLevels] = {nullptr}, *scb[kMaxLevels] = {nullptr}, *prev[kMaxLevels] = {nullptr};
@@ -308,7 +309,11 @@ struct Launch {
     hipStream_t s;
     int entry = -1;
     hipEvent_t a = nullptr, b = nullptr;
+    std::string kname_s;
+    const char* kname = "";
+    const char* label = nullptr;
     Launch(gsa_ctx* ctx, hipStream_t st, const char* kernel, const char* layer, double flops, double bytes) : c(ctx), s(st) {
+        kname_s = kernel; kname = kname_s.c_str(); label = layer;
         if (!c->prof) return;
         std::string key = kernel;
         if (c->prof > 1 && layer) { key += " | "; key += layer; }
@@ -333,6 +338,19 @@ struct Launch {
         (void)hipEventRecord(a, s);
     }
     ~Launch() {
+#ifdef GSA_STAMP
+        if (c->stamps && label && strstr(kname, "conv")) {   // diagnostic build: per-phase wave-cycle sums
+            (void)hipStreamSynchronize(s);
+            unsigned long long h[16];
+            (void)hipMemcpy(h, c->stamps, sizeof h, hipMemcpyDeviceToHost);
+            (void)hipMemset(c->stamps, 0, sizeof h);
+            if (h[15]) {
+                const double w = (double)h[15];
+                fprintf(stderr, "STAMP %-40s %-16s waves %8llu  load %7.0f  write %6.0f  bar %6.0f  blocks %8.0f  epi %7.0f\n", kname,
+                        label, h[15], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w);
+            }
+        }
+#endif
         if (entry < 0) return;
         (void)hipEventRecord(b, s);
         c->prof_events.push_back(ProfEvent{a, b, entry});
@@ -692,6 +710,10 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
         if (int rc = dev_alloc(c, N * maxC, &c->stat_acc, T)) return rc;
         HIP_TRY(hipMemset(c->stat_acc, 0, N * maxC * sizeof(StatPart)));
     }
+    {
+        if (int rc = dev_alloc(c, 16, &c->stamps, T)) return rc;
+        HIP_TRY(hipMemset(c->stamps, 0, 16 * sizeof(unsigned long long)));
+    }
     if (c->d_ready) {
         for (int i = 0; i < c->d_n; ++i) {
             const DecLevelDev& d = c->dl[i];
@@ -745,7 +767,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 if (!B.has_conv1) {
                     pp.src = c->constant; pp.src_per_sample = 0; pp.blur = nullptr;
                 } else {
-                    ConvParams cp{};
+                    ConvParams cp{}; cp.stamps = c->stamps;
                     cp.src0 = c->x2[l - 1]; cp.aff0 = c->aff2[l - 1]; cp.C0 = Cin;
                     cp.Hs = R / 2; cp.Ws = R / 2; cp.H = R; cp.W = R;
                     cp.wpk = B.w1; cp.Cout = C; cp.out = c->t_raw;
@@ -768,7 +790,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 HIP_TRY(launch_post(pp, n, s));
                 prow = post_prow(R, R, C);
             } else {
-                ConvParams cp{};
+                ConvParams cp{}; cp.stamps = c->stamps;
                 cp.src0 = c->x1; cp.aff0 = c->aff1; cp.C0 = C;
                 cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
                 cp.wpk = B.w2; cp.Cout = C; cp.out = c->x2[l];
@@ -813,7 +835,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
         const int R = 4 << i;
         const double px = N * R * R;
         {   // cvt_block: conv3x3+bias -> BN -> LeakyReLU (Dropout is identity at inference)
-            ConvParams cp{};
+            ConvParams cp{}; cp.stamps = c->stamps;
             cp.src0 = fsrc[i]; cp.aff0 = faff ? faff[i] : nullptr; cp.C0 = d.I;
             cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
             cp.wpk = d.cvt_w; cp.Cout = d.F; cp.out = c->cvt[i];
@@ -826,7 +848,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             const int R2 = 2 * R;
             const double px2 = 4 * px;
             {   // ResBlock conv a (+ fused 1x1 shortcut) on nearest-x2(concat(prev, cvt))
-                ConvParams cp{};
+                ConvParams cp{}; cp.stamps = c->stamps;
                 if (i > 0) { cp.src0 = c->prev[i - 1]; cp.C0 = d.F; cp.src1 = c->cvt[i]; cp.C1 = d.F; }
                 else { cp.src0 = c->cvt[i]; cp.C0 = d.F; }
                 cp.Hs = R; cp.Ws = R; cp.up = 1; cp.H = R2; cp.W = R2;
@@ -839,7 +861,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, d.has_sc, n, s));
             }
             {   // ResBlock conv b, + shortcut
-                ConvParams cp{};
+                ConvParams cp{}; cp.stamps = c->stamps;
                 cp.src0 = c->ya[i]; cp.C0 = d.cs;
                 cp.Hs = R2; cp.Ws = R2; cp.H = R2; cp.W = R2;
                 cp.wpk = d.b_w; cp.Cout = d.cs; cp.out = c->prev[i];

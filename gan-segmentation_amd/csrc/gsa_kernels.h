@@ -36,7 +36,8 @@ struct ConvParams {
     const float* resid; int resid_up;   // resid_up: residual lives at half resolution (identity shortcut)
     // fused 1x1 shortcut of DecoderResBlock (second output)
     const float* wsc; const float* sc_bias; float* out_sc;
-    int tiles_x;
+    int tiles_x, tiles_y, groups, total_tiles;   // filled by the launcher
+    unsigned long long* stamps;   // diagnostic build (-DGSA_STAMP) only: per-phase cycle sums
 };
 
 struct PostParams {

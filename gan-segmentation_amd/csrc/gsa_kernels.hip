@@ -28,6 +28,18 @@ namespace gsa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (make stamp): s_memtime stamps at the phase boundaries of the conv
+// kernel, summed per phase into ConvParams::stamps.  No stamp executes in the product build.
+#ifdef GSA_STAMP
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_DECL unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP_FLUSH(nph) do { if (p.stamps && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < (nph); ++i_) atomicAdd(&p.stamps[i_], stamp_t[i_ + 1] - stamp_t[i_]); atomicAdd(&p.stamps[15], 1ull); } } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#define STAMP_DECL do {} while (0)
+#define STAMP_FLUSH(nph) do {} while (0)
+#endif
+
 __device__ __forceinline__ float lrelu(float v) { return v > 0.0f ? v : 0.2f * v; }
 
 // rint(v * scale) as a wrapping 64-bit integer (1.5*2^52 magic constant); order-independent sums
@@ -98,7 +110,16 @@ __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const floa
 
 // ------------------------------------------------------------------------------------------
 // conv3x3 (pad 1) as implicit GEMM on v_mfma_f32_16x16x4_f32.
-// Workgroup = WM*WN waves, output tile TH x TW pixels x COUT_T = 16*NT*WN channels.
+//
+// Workgroup = WM*WN waves; one work tile = TH x TW output pixels x COUT_T = 16*NT*WN channels
+// of one sample.  Workgroups are PERSISTENT: each walks a contiguous range of work tiles and
+// software-pipelines across (tile, 16-channel block) items -- the global loads of item i+1 are
+// in flight during the MFMAs and the epilogue stores of item i.  (One workgroup per tile made
+// whole generations of workgroups alternate between "everyone loads" and "everyone computes":
+// in-kernel stamps showed 57k-cycle load phases and 7x-stretched MFMA phases on the 16-channel
+// layers.)
+struct WorkTile { int n, g, y0, x0, row; };   // row = tile index inside the image
+
 template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
     constexpr int NW = WM * WN, NTHR = 64 * NW;
@@ -112,32 +133,48 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
     constexpr int AIT = (LH * LW + NTHR - 1) / NTHR;
     constexpr int BIT = (NB4 + NTHR - 1) / NTHR;
     constexpr int SIT = (Q * 64 + NTHR - 1) / NTHR;   // shortcut weights: Q*256 floats
+    constexpr int FIT = (512 + NTHR - 1) / NTHR;      // AdaIN table: up to 512 input channels
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sB = sA + LH * RS;                    // [q][tap][ci][16][cg]
     float* sS = sB + Q * SEG;                    // SC: [q][ci][16][cg]
-    float4* sAff = reinterpret_cast<float4*>(sS + (SC ? Q * 256 : 0));   // [C0] (mean, A, B, -)
+    f32x4* sAff = reinterpret_cast<f32x4*>(sS + (SC ? Q * 256 : 0));   // [C0] (mean, A, B, -)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
-    const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x % p.tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW;
-    const int g = blockIdx.y, n = blockIdx.z;
     const int i16 = lane & 15, kq = lane >> 4;
 
-    TilePixel tp[AIT];
+    // contiguous range of work tiles of this workgroup; order (n, g, ty, tx), tx fastest
+    const int chunk = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int w_begin = blockIdx.x * chunk;
+    const int w_end = min(p.total_tiles, w_begin + chunk);
+    if (w_begin >= w_end) return;
+    auto decode = [&](int w) {
+        WorkTile t;
+        const int tx = w % p.tiles_x;
+        int r = w / p.tiles_x;
+        const int ty = r % p.tiles_y;
+        r /= p.tiles_y;
+        t.g = r % p.groups;
+        t.n = r / p.groups;
+        t.y0 = ty * TH; t.x0 = tx * TW;
+        t.row = ty * p.tiles_x + tx;
+        return t;
+    };
+    auto tile_pixels = [&](const WorkTile& t, TilePixel (&tp)[AIT]) {
 #pragma unroll
-    for (int it = 0; it < AIT; ++it) {
-        const int idx = tid + it * NTHR;
-        tp[it].pix = -1; tp[it].lds = -1;
-        if (idx < LH * LW) {
+        for (int it = 0; it < AIT; ++it) {
+            const int idx = tid + it * NTHR;
             const int ly = idx / LW, lx = idx % LW;
-            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
-            tp[it].lds = ly * RS + lx * 16;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) tp[it].pix = (n * p.Hs + (gy >> p.up)) * p.Ws + (gx >> p.up);
+            const int gy = t.y0 - 1 + ly, gx = t.x0 - 1 + lx;
+            const bool stage = idx < LH * LW;
+            const bool inside = stage && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            tp[it].lds = stage ? ly * RS + lx * 16 : -1;
+            tp[it].pix = inside ? (t.n * p.Hs + (gy >> p.up)) * p.Ws + (gx >> p.up) : -1;
         }
-    }
+    };
+
     int abase[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -158,9 +195,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         }
 
     const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4;
-    f32x4 ra[AIT][4], rb[BIT], rs[SC ? SIT : 1];
+    const bool has_aff = p.aff0 != nullptr;
+    f32x4 ra[AIT][4], rb[BIT], rs[SC ? SIT : 1], rf[FIT];
+    STAMP_DECL;
+    STAMP(0);
 
-    auto load_block = [&](int cb) {
+    // prefetch of one (tile, block) item into registers -- every load unconditional
+    auto load_item = [&](const WorkTile& t, int cb, const TilePixel (&tp)[AIT]) {
         const bool first = cb < nblk0;
         const float* src = first ? p.src0 : p.src1;
         const int Cs = first ? p.C0 : p.C1;
@@ -171,24 +212,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         for (int j = 0; j < BIT; ++j) {
             const int i = min(tid + j * NTHR, NB4 - 1);    // clamped: duplicates rewrite the same value
             const int q = i / (SEG / 4), r = i % (SEG / 4);
-            rb[j] = reinterpret_cast<const f32x4*>(p.wpk + ((size_t)(g * Q + q) * nblk + cb) * SEG)[r];
+            rb[j] = reinterpret_cast<const f32x4*>(p.wpk + ((size_t)(t.g * Q + q) * nblk + cb) * SEG)[r];
         }
         if (SC) {
 #pragma unroll
             for (int j = 0; j < SIT; ++j) {
                 const int i = min(tid + j * NTHR, Q * 64 - 1);
                 const int q = i / 64, r = i % 64;
-                rs[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)(g * Q + q) * nblk + cb) * 256)[r];
+                rs[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)(t.g * Q + q) * nblk + cb) * 256)[r];
             }
         }
-    };
-    auto write_block = [&](int cb) {
-        if (cb < nblk0 && p.aff0) {      // wave-uniform
+        if (has_aff) {     // AdaIN table of the item's sample (copied to LDS when the sample changes)
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<true>(sA, ra[it], sAff + cb * 16, tp[it]);
+            for (int j = 0; j < FIT; ++j)
+                rf[j] = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0)[min(tid + j * NTHR, p.C0 - 1)];
+        }
+    };
+    auto write_aff = [&]() {
+#pragma unroll
+        for (int j = 0; j < FIT; ++j) sAff[min(tid + j * NTHR, p.C0 - 1)] = rf[j];
+    };
+    auto write_item = [&](int cb, const TilePixel (&tp)[AIT]) {
+        if (cb < nblk0 && has_aff) {      // wave-uniform
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) store_pixel<true>(sA, ra[it], reinterpret_cast<const float4*>(sAff) + cb * 16, tp[it]);
         } else {
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<false>(sA, ra[it], sAff, tp[it]);
+            for (int it = 0; it < AIT; ++it) store_pixel<false>(sA, ra[it], reinterpret_cast<const float4*>(sAff), tp[it]);
         }
 #pragma unroll
         for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB)[min(tid + j * NTHR, NB4 - 1)] = rb[j];
@@ -198,16 +248,40 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         }
     };
 
-    load_block(0);
-    if (p.aff0) {
-        const float4* ga = reinterpret_cast<const float4*>(p.aff0 + (size_t)n * p.C0);
-        for (int i = tid; i < p.C0; i += NTHR) sAff[i] = ga[i];
+    WorkTile tc = decode(w_begin);
+    TilePixel tp[AIT], tpn[AIT];
+    tile_pixels(tc, tp);
+    load_item(tc, 0, tp);
+    int n_aff = tc.n;
+    if (has_aff) {
+        write_aff();
         __syncthreads();
     }
-    write_block(0);
+#ifdef GSA_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(1);                                      // [0,1): prologue + first global loads landed
+    write_item(0, tp);
+    STAMP(2);                                      // [1,2): first LDS write
     __syncthreads();
-    for (int cb = 0; cb < nblk; ++cb) {
-        load_block(min(cb + 1, nblk - 1));         // in flight during the MFMAs below (the last one is a harmless reload)
+    STAMP(3);                                      // [2,3): barrier
+
+    int w = w_begin, cb = 0;
+    while (true) {
+        // ---- the next item (or a harmless reload of this one when it is the last)
+        int w2 = w, cb2 = cb + 1;
+        if (cb2 == nblk) { cb2 = 0; w2 = w + 1; }
+        const bool has_next = w2 < w_end;
+        if (!has_next) { w2 = w; cb2 = cb; }
+        WorkTile tn = tc;
+        if (w2 != w) {
+            tn = decode(w2);
+            tile_pixels(tn, tpn);
+        } else {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) tpn[it] = tp[it];
+        }
+        load_item(tn, cb2, tpn);                   // in flight during the MFMAs and the epilogue below
         __builtin_amdgcn_sched_barrier(0);         // keep the consumers of those loads below the MFMAs
         // ---- MFMA: K order (tap, cg, ci) inside the block
 #pragma unroll
@@ -239,98 +313,116 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (cb + 1 < nblk) {
-            __syncthreads();          // every wave has finished reading this block
-            write_block(cb + 1);
-            __syncthreads();
-        }
-    }
 
-    // ---- epilogue.  C layout: lane -> (channel = lane&15, patch row = lane>>4), reg -> patch column.
-    // Every global load (noise, residual, per-channel constants) is issued before the first
-    // store: the compiler cannot move a load above a store that might alias it.
-    const int prow_in_patch = lane >> 4;
-    size_t pixs[MT];
-    float4 nzs[EPI == EPI_SYNTH ? MT : 1];
+        if (cb == nblk - 1) {
+            // ---- epilogue of tile tc.  C layout: lane -> (channel = lane&15, patch row = lane>>4),
+            // reg -> patch column.  Every global load (noise, residual, per-channel constants) is
+            // issued before the first store: a load cannot move above a store that might alias it.
+            const int prow_in_patch = lane >> 4;
+            size_t pixs[MT];
+            float4 nzs[EPI == EPI_SYNTH ? MT : 1];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
-        const int y = y0 + pr * 4 + prow_in_patch, x = x0 + pc * 4;
-        pixs[mt] = (size_t)(n * p.H + y) * p.W + x;
-        if (EPI == EPI_SYNTH) nzs[mt] = *reinterpret_cast<const float4*>(p.noise + pixs[mt]);
-    }
-    float e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int co = g * COUT_T + (wn * NT + nt) * 16 + i16;
-        e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = 0.f;
-        if (EPI == EPI_SYNTH) { e0[nt] = p.nscale[co]; e1[nt] = p.nbias[co]; }
-        if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
-        if (SC) scb[nt] = p.sc_bias[co];
-    }
-    float rr[EPI == EPI_DEC ? MT : 1][EPI == EPI_DEC ? NT : 1][4];
-    const bool has_resid = EPI == EPI_DEC && p.resid != nullptr;
-    if (EPI == EPI_DEC && has_resid) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
-            const int y = y0 + pr * 4 + prow_in_patch, x = x0 + pc * 4;
+            for (int mt = 0; mt < MT; ++mt) {
+                const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
+                const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4;
+                pixs[mt] = (size_t)(tc.n * p.H + y) * p.W + x;
+                if (EPI == EPI_SYNTH) nzs[mt] = *reinterpret_cast<const float4*>(p.noise + pixs[mt]);
+            }
+            float e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int co = g * COUT_T + (wn * NT + nt) * 16 + i16;
+                const int co = tc.g * COUT_T + (wn * NT + nt) * 16 + i16;
+                e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = 0.f;
+                if (EPI == EPI_SYNTH) { e0[nt] = p.nscale[co]; e1[nt] = p.nbias[co]; }
+                if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
+                if (SC) scb[nt] = p.sc_bias[co];
+            }
+            float rr[EPI == EPI_DEC ? MT : 1][EPI == EPI_DEC ? NT : 1][4];
+            const bool has_resid = EPI == EPI_DEC && p.resid != nullptr;
+            if (EPI == EPI_DEC && has_resid) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const size_t rp = p.resid_up ? (size_t)(n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + ((x + r) >> 1)
-                                                 : pixs[mt] + r;
-                    rr[mt][nt][r] = p.resid[rp * p.Cout + co];
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
+                    const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int co = tc.g * COUT_T + (wn * NT + nt) * 16 + i16;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const size_t rp = p.resid_up
+                                                  ? (size_t)(tc.n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + ((x + r) >> 1)
+                                                  : pixs[mt] + r;
+                            rr[mt][nt][r] = p.resid[rp * p.Cout + co];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = tc.g * COUT_T + (wn * NT + nt) * 16 + i16;
+                unsigned long long I1 = 0, I2 = 0;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const size_t pix = pixs[mt];
+                    float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+                    if (EPI == EPI_SYNTH) {
+                        const float nzv[4] = {nzs[mt].x, nzs[mt].y, nzs[mt].z, nzs[mt].w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float t = e0[nt] * nzv[r];
+                            v[r] = lrelu((v[r] + t) + e1[nt]);
+                        }
+                        const float s = (v[0] + v[1]) + (v[2] + v[3]);
+                        const float q = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                        I1 += to_fixed(s, kStatScale1);
+                        I2 += to_fixed(q, kStatScale2);
+                    }
+                    if (EPI == EPI_DEC) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float yv = v[r] + e0[nt];
+                            v[r] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
+                            if (has_resid) v[r] = rr[mt][nt][r] + v[r];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p.out[(pix + r) * p.Cout + co] = v[r];
+                    if (SC) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) p.out_sc[(pix + r) * p.Cout + co] = accs[mt][nt][r] + scb[nt];
+                    }
+                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (SC) accs[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (EPI == EPI_SYNTH) {
+                    I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
+                    I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
+                    if (lane < 16) {
+                        StatPart sp; sp.s1 = I1; sp.s2 = I2;
+                        p.partials[((size_t)tc.n * p.prow + tc.row * WM + wm) * p.Cout + co] = sp;
+                    }
                 }
             }
         }
+        if (!has_next) break;
+        __syncthreads();              // every wave has finished reading this item's LDS image
+        if (has_aff && tn.n != n_aff) {   // wave-uniform: the next item belongs to another sample
+            write_aff();
+            n_aff = tn.n;
+            __syncthreads();
+        }
+        write_item(cb2, tpn);
+        __syncthreads();
+        tc = tn; w = w2; cb = cb2;
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) tp[it] = tpn[it];
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int co = g * COUT_T + (wn * NT + nt) * 16 + i16;
-        unsigned long long I1 = 0, I2 = 0;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const size_t pix = pixs[mt];
-            float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
-            if (EPI == EPI_SYNTH) {
-                const float nzv[4] = {nzs[mt].x, nzs[mt].y, nzs[mt].z, nzs[mt].w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float t = e0[nt] * nzv[r];
-                    v[r] = lrelu((v[r] + t) + e1[nt]);
-                }
-                const float s = (v[0] + v[1]) + (v[2] + v[3]);
-                const float q = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
-                I1 += to_fixed(s, kStatScale1);
-                I2 += to_fixed(q, kStatScale2);
-            }
-            if (EPI == EPI_DEC) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float yv = v[r] + e0[nt];
-                    v[r] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
-                    if (has_resid) v[r] = rr[mt][nt][r] + v[r];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p.out[(pix + r) * p.Cout + co] = v[r];
-            if (SC) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p.out_sc[(pix + r) * p.Cout + co] = accs[mt][nt][r] + scb[nt];
-            }
-        }
-        if (EPI == EPI_SYNTH) {
-            I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
-            I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
-            if (lane < 16) {
-                StatPart sp; sp.s1 = I1; sp.s2 = I2;
-                p.partials[((size_t)n * p.prow + blockIdx.x * WM + wm) * p.Cout + co] = sp;
-            }
-        }
-    }
+    STAMP(4);                                      // [3,4): all items (MFMA, staging, epilogues)
+#ifdef GSA_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(5);                                      // [4,5): last stores retired
+    STAMP_FLUSH(5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -837,6 +929,7 @@ template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC>
 static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int Q = NT * WN, COUT_T = 16 * Q;
     constexpr int RS = (TW + 2) * 16 + 8;
+    if (p.C0 > 512 && p.aff0) return hipErrorInvalidValue;   // AdaIN table registers sized for <= 512 channels
     const size_t lds = sizeof(float) * ((TH + 2) * RS + Q * 9 * 256 + (SC ? Q * 256 : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
     auto kern = conv3x3_mfma<TH, TW, WM, WN, NT, EPI, SC>;
     static bool attr_done = false;
@@ -845,11 +938,25 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
+    static int wgs_per_cu = 0, num_cus = 0;
+    static size_t occ_lds = ~(size_t)0;
+    if (occ_lds != lds) {     // resident workgroups per CU for this LDS footprint
+        int dev = 0, k = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, reinterpret_cast<const void*>(kern), 64 * WM * WN, lds);
+        if (e != hipSuccess) return e;
+        wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
+        occ_lds = lds;
+    }
     ConvParams q = p;
     q.tiles_x = p.W / TW;
-    q.prow = (p.H / TH) * (p.W / TW) * WM;
-    dim3 grid((p.H / TH) * (p.W / TW), p.Cout / COUT_T, n);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, q);
+    q.tiles_y = p.H / TH;
+    q.groups = p.Cout / COUT_T;
+    q.prow = q.tiles_x * q.tiles_y * WM;
+    q.total_tiles = q.tiles_x * q.tiles_y * q.groups * n;
+    const int grid = q.total_tiles < num_cus * wgs_per_cu ? q.total_tiles : num_cus * wgs_per_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, s, q);
     return hipGetLastError();
 }
 
