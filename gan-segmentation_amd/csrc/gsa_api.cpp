@@ -206,6 +206,37 @@ std::vector<float> pack_deconv(const float* w, int I, int O, float std, bool us,
     return out;
 }
 
+// nearest-x2 + conv3x3 (OIHW (O,I,3,3)) in sub-pixel form: the equivalent stride-2 transposed
+// 4x4 kernel Wd[a][b] = sum_{ky in S(a)} sum_{kx in S(b)} W[ky][kx], S(0)={2} S(1)={1,2}
+// S(2)={0,1} S(3)={0}; fp32 sums, ky then kx ascending, left to right (canonical order,
+// DESIGN.md).  Packed like a deconv: [O/16][I/16][tap16][ci][16][cg].
+std::vector<float> pack_upconv(const float* w, int O, int I, float std, bool us, float lr) {
+    static const int S[4][2] = {{2, -1}, {1, 2}, {0, 1}, {0, -1}};
+    std::vector<float> out((size_t)O * I * 16);
+    const int nblk = I / 16, G = O / 16;
+    for (int g = 0; g < G; ++g)
+        for (int cb = 0; cb < nblk; ++cb)
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b)
+                    for (int ci = 0; ci < 4; ++ci)
+                        for (int n = 0; n < 16; ++n)
+                            for (int cg = 0; cg < 4; ++cg) {
+                                const int o = g * 16 + n, ch = cb * 16 + cg * 4 + ci;
+                                const float* wk = w + ((size_t)o * I + ch) * 9;
+                                float sum = 0.0f;
+                                bool first = true;
+                                for (int i = 0; i < 2; ++i)
+                                    for (int j = 0; j < 2; ++j) {
+                                        if (S[a][i] < 0 || S[b][j] < 0) continue;
+                                        const float e = eff(wk[S[a][i] * 3 + S[b][j]], std, us, lr);
+                                        sum = first ? e : sum + e;
+                                        first = false;
+                                    }
+                                out[((((((size_t)g * nblk + cb) * 16 + a * 4 + b) * 4 + ci) * 16 + n) * 4) + cg] = sum;
+                            }
+    return out;
+}
+
 // 1x1 shortcut (O,I,1,1) -> [O/16][I/16][ci][16][cg]
 std::vector<float> pack_conv1(const float* w, int O, int I) {
     const int ct = 16;
@@ -491,7 +522,7 @@ int gsa_generator_commit(gsa_ctx* c) {
                 h = pack_deconv(w, Cin, C, std, us, 1.0f);
             } else {
                 NEED(P, std::string(nm) + "_weight", (size_t)Cin * C * 9, &w);
-                h = pack_conv3(w, C, Cin, std, us, 1.0f);
+                h = R >= 16 ? pack_upconv(w, C, Cin, std, us, 1.0f) : pack_conv3(w, C, Cin, std, us, 1.0f);
             }
             if (int rc = upload(c, h, &B.w1, T)) return rc;
             snprintf(nm, sizeof nm, "%d_blur_1_w_kernel", R);
@@ -635,7 +666,7 @@ int gsa_decoder_commit(gsa_ctx* c) {
             const std::string pf = "main_block_" + std::to_string(i) + ".1.base_layers";
             NEED(P, pf + ".0.weight", (size_t)d.cs * d.in_c * 9, &w);
             NEED(P, pf + ".0.bias", (size_t)d.cs, &b);
-            h = pack_conv3(w, d.cs, d.in_c, 1.0f, false, 1.0f);
+            h = (8 << i) >= 16 ? pack_upconv(w, d.cs, d.in_c, 1.0f, false, 1.0f) : pack_conv3(w, d.cs, d.in_c, 1.0f, false, 1.0f);
             if (int rc = upload(c, h, &d.a_w, T)) return rc;
             h.assign(b, b + d.cs);
             if (int rc = upload(c, h, &d.a_b, T)) return rc;
@@ -771,12 +802,13 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                     cp.src0 = c->x2[l - 1]; cp.aff0 = c->aff2[l - 1]; cp.C0 = Cin;
                     cp.Hs = R / 2; cp.Ws = R / 2; cp.H = R; cp.W = R;
                     cp.wpk = B.w1; cp.Cout = C; cp.out = c->t_raw;
-                    if (B.is_deconv) {
-                        snprintf(layer, sizeof layer, "g.%d.deconv_1", R);
+                    if (B.is_deconv || R >= 16) {
+                        // Deconvolution 4x4 s2, or nearest-x2 + conv3x3 in sub-pixel form (same kernel)
+                        snprintf(layer, sizeof layer, B.is_deconv ? "g.%d.deconv_1" : "g.%d.conv_1", R);
                         static thread_local char kn[64];
-                        snprintf(kn, sizeof kn, "deconv4x4_mfma<%s>", deconv_geom_name(C));
+                        snprintf(kn, sizeof kn, "subpixel_mfma<%s,raw>", subpixel_geom_name(R, R, C, n));
                         Launch lp(c, s, kn, layer, 2.0 * px * C * Cin * 4, 4.0 * (px / 4 * Cin + px * C));
-                        HIP_TRY(launch_deconv4x4(cp, n, s));
+                        HIP_TRY(launch_subpixel(cp, EPI_RAW, false, n, s));
                     } else {
                         cp.up = 1;
                         snprintf(layer, sizeof layer, "g.%d.conv_1", R);
@@ -856,9 +888,18 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 cp.bias = d.a_b; cp.bn_s = d.a_s; cp.bn_rm = d.a_rm; cp.bn_beta = d.a_beta;
                 if (d.has_sc) { cp.wsc = d.sc_w; cp.sc_bias = d.sc_b; cp.out_sc = c->scb[i]; }
                 snprintf(layer, sizeof layer, "d.main_%d.a", i);
-                Launch lp(c, s, conv_kernel_name(R2, d.cs, n, EPI_DEC, d.has_sc), layer,
-                          2.0 * px2 * d.cs * d.in_c * (9 + (d.has_sc ? 1 : 0)), 4.0 * (px * d.in_c + px2 * d.cs * (d.has_sc ? 2 : 1)));
-                HIP_TRY(launch_conv3x3(cp, EPI_DEC, d.has_sc, n, s));
+                if (R2 >= 16) {   // sub-pixel form: 4 taps per output instead of 9
+                    static thread_local char kn[64];
+                    snprintf(kn, sizeof kn, "subpixel_mfma<%s,dec%s>", subpixel_geom_name(R2, R2, d.cs, n), d.has_sc ? "+sc" : "");
+                    Launch lp(c, s, kn, layer, 2.0 * px2 * d.cs * d.in_c * (4 + (d.has_sc ? 1 : 0)),
+                              4.0 * (px * d.in_c + px2 * d.cs * (d.has_sc ? 2 : 1)));
+                    cp.up = 0;
+                    HIP_TRY(launch_subpixel(cp, EPI_DEC, d.has_sc, n, s));
+                } else {
+                    Launch lp(c, s, conv_kernel_name(R2, d.cs, n, EPI_DEC, d.has_sc), layer,
+                              2.0 * px2 * d.cs * d.in_c * (9 + (d.has_sc ? 1 : 0)), 4.0 * (px * d.in_c + px2 * d.cs * (d.has_sc ? 2 : 1)));
+                    HIP_TRY(launch_conv3x3(cp, EPI_DEC, d.has_sc, n, s));
+                }
             }
             {   // ResBlock conv b, + shortcut
                 ConvParams cp{}; cp.stamps = c->stamps;

@@ -59,7 +59,7 @@ struct FinalizeParams {
 
 // launches (all stream-ordered, no sync)
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);
-hipError_t launch_deconv4x4(const ConvParams& p, int n, hipStream_t s);
+hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);   // deconv4x4s2 / sub-pixel up+conv3x3
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s);
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);
 hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_t s);
@@ -79,6 +79,6 @@ hipError_t launch_final_conv(const float* src0, int C0, const float* src1, int C
 int conv_stat_rows(int H, int W, int Cout, int n);   // statistic partial rows per sample written by conv3x3 EPI_SYNTH
 int post_prow(int H, int W, int C);                  // ... written by the post kernel
 const char* conv_geom_name(int H, int W, int Cout, int n);   // "tile16,cout64" -- for profile labels
-const char* deconv_geom_name(int Cout);
+const char* subpixel_geom_name(int H, int W, int Cout, int n);
 
 }  // namespace gsa

@@ -25,6 +25,7 @@
  *   argmax of SegSolver.predict ....... seg_solver.py:326
  *
  * Canonical arithmetic (all fp32 round-to-nearest, no contraction except explicit fmaf):
+ *   up+conv (nearest x2 then 3x3, outputs >= 16 px): sub-pixel form, see pack_upconv()
  *   conv   acc=0; for cb in Cin/16: for ky: for kx: for c in 16: acc=fmaf(in[16cb+c],w,acc)
  *          (channels in blocks of 16, the taps inside a block; out-of-image taps skipped,
  *          which equals adding +0; 1x1 convs and dense layers are plain k-ordered chains)
@@ -77,7 +78,7 @@ typedef struct {
 typedef struct {
     int C, Cin, R;
     int has_conv1, is_deconv;
-    float* w1;      /* packed conv_1 / deconv_1 */
+    float* w1;      /* packed conv_1 / deconv_1 (sub-pixel deconv packing when R >= 16) */
     float* blur;    /* [C][9] */
     float* nscale[2];
     float* nbias[2];
@@ -196,6 +197,37 @@ static float* pack_deconv(const float* w, int I, int O, float std, int use_std, 
                 for (int o = 0; o < O; ++o)
                     out[(((size_t)cb * 16 + t) * CB + ci) * O + o] =
                         eff(w[((size_t)(cb * CB + ci) * O + o) * 16 + t], std, use_std, lr);
+    return out;
+}
+
+/* nearest-x2 upsample followed by a 3x3 conv (reference networks_stylegan.py:22-27,
+ * networks_seg.py:86-88) in its SUB-PIXEL form: the output pixel (2y+dy, 2x+dx) only sees the
+ * 2x2 input pixels {y-1+dy, y+dy} x {x-1+dx, x+dx}, with the 3x3 taps that fall on the same
+ * input pixel pre-summed.  That is exactly a stride-2 transposed conv with the 4x4 kernel
+ *   Wd[a][b] = sum_{ky in S(a)} sum_{kx in S(b)} W[ky][kx],  S(0)={2} S(1)={1,2} S(2)={0,1} S(3)={0}
+ * (fp32 sums, ky then kx ascending, left to right), 2.25x fewer MACs than the 9-tap form.
+ * Used for outputs of 16 px and larger; exact algebra, rounding differs by a few ulp.
+ * conv OIHW (O,I,3,3) -> deconv packing [(cb*16 + tap16)*CB + c][O] */
+static float* pack_upconv(const float* w, int O, int I, float std, int use_std, float lr) {
+    static const int S[4][2] = {{2, -1}, {1, 2}, {0, 1}, {0, -1}};
+    float* out = (float*)malloc(sizeof(float) * (size_t)O * I * 16);
+    for (int cb = 0; cb < I / CB; ++cb)
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b)
+                for (int ci = 0; ci < CB; ++ci)
+                    for (int o = 0; o < O; ++o) {
+                        const float* wk = w + ((size_t)o * I + cb * CB + ci) * 9;
+                        float sum = 0.0f;
+                        int first = 1;
+                        for (int i = 0; i < 2; ++i)
+                            for (int j = 0; j < 2; ++j) {
+                                if (S[a][i] < 0 || S[b][j] < 0) continue;
+                                const float e = eff(wk[S[a][i] * 3 + S[b][j]], std, use_std, lr);
+                                sum = first ? e : sum + e;
+                                first = 0;
+                            }
+                        out[(((size_t)cb * 16 + a * 4 + b) * CB + ci) * O + o] = sum;
+                    }
     return out;
 }
 
@@ -360,7 +392,7 @@ GSAO_API int gsao_generator_commit(gsao_ctx* c) {
             int rc = get_std(c, t, pf, &std); if (rc) return rc;
             snprintf(nm, sizeof nm, "%s_weight", pf);
             if (B->is_deconv) { NEED(t, nm, (int64_t)Cin * C * 16, &w); B->w1 = pack_deconv(w, Cin, C, std, us, 1.0f); }
-            else { NEED(t, nm, (int64_t)Cin * C * 9, &w); B->w1 = pack_conv(w, C, Cin, 3, std, us, 1.0f); }
+            else { NEED(t, nm, (int64_t)Cin * C * 9, &w); B->w1 = R >= 16 ? pack_upconv(w, C, Cin, std, us, 1.0f) : pack_conv(w, C, Cin, 3, std, us, 1.0f); }
             snprintf(nm, sizeof nm, "%d_blur_1_w_kernel", R); NEED(t, nm, (int64_t)C * 9, &w);
             B->blur = copy_plain(w, (int64_t)C * 9);
         }
@@ -635,6 +667,7 @@ GSAO_API int gsao_generator_forward(gsao_ctx* c, void* stream, int32_t n, const 
                     } else {
                         /* xb holds the affine-applied previous feature */
                         if (B->is_deconv) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc);
+                        else if (R >= 16) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc);   /* sub-pixel up+conv */
                         else conv3x3(xb, R / 2, R / 2, Cin, 1, B->w1, C, xc);
                         blur3x3(xc, R, R, C, B->blur, xa);
                     }
@@ -737,7 +770,7 @@ GSAO_API int gsao_decoder_commit(gsao_ctx* c) {
             const int second = c->d_bn ? 3 : 2;
             snprintf(pf, sizeof pf, "main_block_%d.1.base_layers", i);
             snprintf(nm, sizeof nm, "%s.0.weight", pf); NEED(t, nm, (int64_t)d->cs * d->in_c * 9, &w);
-            d->a_w = pack_conv(w, d->cs, d->in_c, 3, 1.0f, 0, 1.0f);
+            d->a_w = (8 << i) >= 16 ? pack_upconv(w, d->cs, d->in_c, 1.0f, 0, 1.0f) : pack_conv(w, d->cs, d->in_c, 3, 1.0f, 0, 1.0f);
             snprintf(nm, sizeof nm, "%s.0.bias", pf); NEED(t, nm, d->cs, &b); d->a_b = copy_plain(b, d->cs);
             snprintf(nm, sizeof nm, "%s.1", pf);
             { int rc = load_bn(c, nm, d->cs, &d->a_s, &d->a_rm, &d->a_beta); if (rc) return rc; }
@@ -814,7 +847,8 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                 /* main_block: nearest x2 -> DecoderResBlock, reference :7-46, :86-88 */
                 const int R2 = 2 * R;
                 const size_t np2 = (size_t)R2 * R2;
-                conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya);
+                if (R2 >= 16) deconv4x4s2(cat, R, R, d->in_c, d->a_w, d->cs, ya);   /* sub-pixel up+conv */
+                else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya);
                 bias_bn_act(ya, np2, d->cs, d->a_b, d->a_s, d->a_rm, d->a_beta);
                 conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb);
                 bias_bn_act(yb, np2, d->cs, d->b_b, d->b_s, d->b_rm, d->b_beta);
