@@ -105,6 +105,7 @@ struct gsa_ctx {
     Aff* aff2[kMaxLevels] = {nullptr};
     StatPart* partials = nullptr;
     StatPart* stat_acc = nullptr;
+    unsigned* stat_tickets = nullptr;
     unsigned long long* stamps = nullptr;   // diagnostic build only
     float* din[kMaxLevels] = {nullptr};
     float* cvt[kMaxLevels] = {nullptr};
@@ -740,6 +741,8 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
         if (int rc = dev_alloc(c, N * prow_elems, &c->partials, T)) return rc;
         if (int rc = dev_alloc(c, N * maxC, &c->stat_acc, T)) return rc;
         HIP_TRY(hipMemset(c->stat_acc, 0, N * maxC * sizeof(StatPart)));
+        if (int rc = dev_alloc(c, N * ((maxC + 63) / 64), &c->stat_tickets, T)) return rc;
+        HIP_TRY(hipMemset(c->stat_tickets, 0, N * ((maxC + 63) / 64) * sizeof(unsigned)));
     }
     {
         if (int rc = dev_alloc(c, 16, &c->stamps, T)) return rc;
@@ -833,7 +836,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 prow = conv_stat_rows(R, R, C, n);
             }
             FinalizeParams fp{};
-            fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C; fp.acc = c->stat_acc;
+            fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C; fp.acc = c->stat_acc; fp.tickets = c->stat_tickets;
             fp.style = c->styles + B.style_off[k]; fp.style_stride = c->style_cols;
             fp.gamma = B.gamma[k]; fp.beta = B.beta[k];
             fp.aff = k == 0 ? c->aff1 : c->aff2[l];

@@ -52,6 +52,7 @@ struct PostParams {
 struct FinalizeParams {
     const StatPart* partials; int prow; int HW; int C;
     StatPart* acc;     // [n][C] zero-initialised accumulators, cleared again by finalize
+    unsigned* tickets; // [n][ceil(C/64)] zero-initialised arrival counters, cleared again by finalize
     const float* style; int style_stride;  // style[n*style_stride + c] = ys, [.. + C + c] = yb
     const float* gamma; const float* beta;
     Aff* aff;   // [n][C]

@@ -683,58 +683,68 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Sum the fixed-point partial rows into acc[n][C] (64-bit integer atomics: order independent,
-// hence deterministic), many blocks per (sample, channel group).
-__global__ __launch_bounds__(256) void stat_reduce_kernel(const StatPart* partials, int prow, int C, StatPart* acc,
-                                                          int rows_per_block) {
+// InstanceNorm statistics -> AdaIN coefficients in ONE launch.  Many blocks per (sample,
+// 64-channel group) sum the fixed-point partial rows into acc[n][C] with 64-bit integer atomics
+// (order independent, hence deterministic); the block that draws the last ticket of its group
+// folds InstanceNorm(eps 1e-5) with the style and clears acc and the ticket for the next layer.
+// Hand-off between blocks: device-scope atomics on both sides (the adds, the ticket, and the
+// final reads via atomic exchange), never plain loads of another block's data.
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p, int rows_per_block) {
     __shared__ unsigned long long sh[2][256];
+    __shared__ int is_last;
     const int n = blockIdx.y;
-    const int cblk = C >= 64 ? 64 : C, nrg = 256 / cblk;
+    const int cblk = p.C >= 64 ? 64 : p.C, nrg = 256 / cblk;
     const int cl = threadIdx.x % cblk, rg = threadIdx.x / cblk;
     const int c = blockIdx.x * 64 + cl;
     unsigned long long I1 = 0, I2 = 0;
-    if (rg < nrg && c < C) {
+    if (rg < nrg && c < p.C) {
         const int r0 = blockIdx.z * rows_per_block;
-        const int r1 = min(prow, r0 + rows_per_block);
-        const StatPart* base = partials + (size_t)n * prow * C + c;
+        const int r1 = min(p.prow, r0 + rows_per_block);
+        const StatPart* base = p.partials + (size_t)n * p.prow * p.C + c;
         for (int r = r0 + rg; r < r1; r += nrg) {
-            const StatPart sp = base[(size_t)r * C];
+            const StatPart sp = base[(size_t)r * p.C];
             I1 += sp.s1; I2 += sp.s2;
         }
     }
     sh[0][threadIdx.x] = I1; sh[1][threadIdx.x] = I2;
     __syncthreads();
-    if (rg == 0 && c < C) {
+    if (rg == 0 && c < p.C) {
         for (int k = 1; k < nrg; ++k) { I1 += sh[0][k * cblk + cl]; I2 += sh[1][k * cblk + cl]; }
-        atomicAdd(&acc[(size_t)n * C + c].s1, I1);
-        atomicAdd(&acc[(size_t)n * C + c].s2, I2);
+        atomicAdd(&p.acc[(size_t)n * p.C + c].s1, I1);
+        atomicAdd(&p.acc[(size_t)n * p.C + c].s2, I2);
     }
-}
-
-// Fold InstanceNorm(eps 1e-5) with the AdaIN style; consumes and clears acc.
-__global__ __launch_bounds__(64) void finalize_kernel(FinalizeParams p) {
-    const int n = blockIdx.y;
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= p.C) return;
-    StatPart* ap = p.acc + (size_t)n * p.C + c;
-    const unsigned long long I1 = ap->s1, I2 = ap->s2;
-    ap->s1 = 0ull; ap->s2 = 0ull;
-    const double inv_hw = 1.0 / (double)p.HW;   // HW is a power of two
-    const double m = (double)(long long)I1 * (1.0 / kStatScale1) * inv_hw;
-    const double e2 = (double)(long long)I2 * (1.0 / kStatScale2) * inv_hw;
-    double var = fma(-m, m, e2);
-    if (!(var > 0.0)) var = 0.0;
-    const float mean_f = (float)m, var_f = (float)var;
-    const float inv = 1.0f / sqrtf(var_f + 1e-5f);
-    const float gsc = p.gamma[c] * inv;
-    const float* st = p.style + (size_t)n * p.style_stride;
-    const float s1 = st[c] + 1.0f;
-    Aff a;
-    a.mean = mean_f;
-    a.A = gsc * s1;
-    a.B = fmaf(p.beta[c], s1, st[p.C + c]);
-    a.pad = 0.0f;
-    p.aff[(size_t)n * p.C + c] = a;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* ticket = p.tickets + n * gridDim.x + blockIdx.x;
+        const unsigned t = atomicAdd(ticket, 1u);
+        is_last = t == gridDim.z - 1;
+        if (is_last) atomicExch(ticket, 0u);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (rg == 0 && c < p.C) {
+        StatPart* ap = p.acc + (size_t)n * p.C + c;
+        I1 = atomicExch(&ap->s1, 0ull);      // read the total and clear it for the next layer
+        I2 = atomicExch(&ap->s2, 0ull);
+        const double inv_hw = 1.0 / (double)p.HW;   // HW is a power of two
+        const double m = (double)(long long)I1 * (1.0 / kStatScale1) * inv_hw;
+        const double e2 = (double)(long long)I2 * (1.0 / kStatScale2) * inv_hw;
+        double var = fma(-m, m, e2);
+        if (!(var > 0.0)) var = 0.0;
+        const float mean_f = (float)m, var_f = (float)var;
+        const float inv = 1.0f / sqrtf(var_f + 1e-5f);
+        const float gsc = p.gamma[c] * inv;
+        const float* st = p.style + (size_t)n * p.style_stride;
+        const float s1 = st[c] + 1.0f;
+        Aff a;
+        a.mean = mean_f;
+        a.A = gsc * s1;
+        a.B = fmaf(p.beta[c], s1, st[p.C + c]);
+        a.pad = 0.0f;
+        p.aff[(size_t)n * p.C + c] = a;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -753,36 +763,71 @@ __global__ void pixelnorm_kernel(const float* z, float* out, int n, int L) {
     for (int k = threadIdx.x; k < L; k += blockDim.x) out[(size_t)s * L + k] = zs[k] * rn;
 }
 
-__global__ __launch_bounds__(64) void dense_kernel(const float* x, const float* WT, const float* b, float* y,
-                                                   int K, int J, int act) {
-    const int j = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
-    if (j >= J) return;
-    const float* xs = x + (size_t)s * K;
-    float acc = 0.0f;
+// Dense layer(s) with the weight panel staged through LDS: one workgroup = 64 output columns
+// x up to 16 samples.  STYLE: column j belongs to style layer col_layer[j] and its input is the
+// truncated latent x_k = latent_avg[k]*(1-psi_l) + w[k]*psi_l (reference :158-163), formed on
+// the fly.  Every output is one k-ordered fmaf chain (canonical order); the K loop only walks
+// LDS, so the 512-step chain costs ~2 us instead of 512 dependent global-load round trips.
+template <bool STYLE>
+__global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const float* WT, const float* b, float* y,
+                                                        int n, int K, int J, int act, const float* avg,
+                                                        const float* psi, const int* col_layer) {
+    constexpr int KC = 128;                         // K rows per LDS pass
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW = smem;                               // [KC][64]
+    float* sX = sW + KC * 64;                       // [16][KC]
+    float* sAvg = sX + 16 * KC;                     // [KC] (STYLE)
+    const int tid = threadIdx.x, jl = tid & 63, ng = tid >> 6;
+    const int j0 = blockIdx.x * 64, j = j0 + jl;
+    const int jc = j < J ? j : J - 1;
+    float ps = 1.0f, om = 0.0f;
+    if (STYLE) { ps = psi[col_layer[jc]]; om = 1.0f - ps; }
+    for (int n0 = 0; n0 < n; n0 += 16) {
+        const int nn = min(16, n - n0);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};        // samples n0 + ng + 4*i
+        for (int k0 = 0; k0 < K; k0 += KC) {
+            __syncthreads();
+            // weight panel: KC x 64 floats = KC*16 float4, coalesced rows of 256 B
+            f32x4 rw[KC * 16 / 256];
+#pragma unroll
+            for (int i = 0; i < KC * 16 / 256; ++i) {
+                const int idx = tid + i * 256, kr = idx >> 4, c4 = (idx & 15) * 4;
+                const int col = min(j0 + c4, J - 4);
+                rw[i] = *reinterpret_cast<const f32x4*>(WT + (size_t)(k0 + kr) * J + col);
+            }
+            for (int idx = tid; idx < nn * KC; idx += 256) sX[idx] = x[(size_t)(n0 + idx / KC) * K + k0 + idx % KC];
+            if (STYLE) for (int idx = tid; idx < KC; idx += 256) sAvg[idx] = avg[k0 + idx];
+#pragma unroll
+            for (int i = 0; i < KC * 16 / 256; ++i) reinterpret_cast<f32x4*>(sW)[tid + i * 256] = rw[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s = ng + 4 * i;
+                if (s < nn) {
+                    float a = acc[i];
+                    const float* xs = sX + s * KC;
 #pragma unroll 8
-    for (int k = 0; k < K; ++k) acc = fmaf(xs[k], WT[(size_t)k * J + j], acc);
-    float v = acc + b[j];
-    y[(size_t)s * J + j] = act ? lrelu(v) : v;
-}
-
-// all style affines in one launch: column j belongs to style layer col_layer[j];
-// x_k = latent_avg[k]*(1-psi_l) + w[k]*psi_l (truncation lerp, reference :158-163)
-__global__ __launch_bounds__(64) void styles_kernel(const float* w, const float* avg, const float* psi,
-                                                    const float* WT, const float* b, const int* col_layer,
-                                                    float* styles, int K, int J) {
-    const int j = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
-    if (j >= J) return;
-    const float ps = psi[col_layer[j]];
-    const float om = 1.0f - ps;
-    const float* ws = w + (size_t)s * K;
-    float acc = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < K; ++k) {
-        const float t0 = avg[k] * om;
-        const float t1 = ws[k] * ps;
-        acc = fmaf(t0 + t1, WT[(size_t)k * J + j], acc);
+                    for (int k = 0; k < KC; ++k) {
+                        float xv = xs[k];
+                        if (STYLE) { const float t0 = sAvg[k] * om; const float t1 = xv * ps; xv = t0 + t1; }
+                        a = fmaf(xv, sW[k * 64 + jl], a);
+                    }
+                    acc[i] = a;
+                }
+            }
+        }
+        if (j < J) {
+            const float bj = b[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s = ng + 4 * i;
+                if (s < nn) {
+                    const float v = acc[i] + bj;
+                    y[(size_t)(n0 + s) * J + j] = act ? lrelu(v) : v;
+                }
+            }
+        }
     }
-    styles[(size_t)s * J + j] = acc + b[j];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1100,12 +1145,8 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
 
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s) {
     const int rpb = 256;
-    dim3 rgrid((p.C + 63) / 64, n, (p.prow + rpb - 1) / rpb);
-    hipLaunchKernelGGL(stat_reduce_kernel, rgrid, dim3(256), 0, s, p.partials, p.prow, p.C, p.acc, rpb);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    dim3 grid((p.C + 63) / 64, n);
-    hipLaunchKernelGGL(finalize_kernel, grid, dim3(64), 0, s, p);
+    dim3 grid((p.C + 63) / 64, n, (p.prow + rpb - 1) / rpb);
+    hipLaunchKernelGGL(finalize_kernel, grid, dim3(256), 0, s, p, rpb);
     return hipGetLastError();
 }
 
@@ -1115,13 +1156,18 @@ hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_
 }
 
 hipError_t launch_dense(const float* x, const float* WT, const float* b, float* y, int n, int K, int J, int act, hipStream_t s) {
-    hipLaunchKernelGGL(dense_kernel, dim3((J + 63) / 64, n), dim3(64), 0, s, x, WT, b, y, K, J, act);
+    if (K % 128 || J % 4) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * (128 * 64 + 16 * 128 + 128);
+    hipLaunchKernelGGL(dense_lds_kernel<false>, dim3((J + 63) / 64), dim3(256), lds, s, x, WT, b, y, n, K, J, act,
+                       (const float*)nullptr, (const float*)nullptr, (const int*)nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_styles(const float* w, const float* avg, const float* psi, const float* WT, const float* b,
                          const int* col_layer, float* styles, int n, int K, int J, hipStream_t s) {
-    hipLaunchKernelGGL(styles_kernel, dim3((J + 63) / 64, n), dim3(64), 0, s, w, avg, psi, WT, b, col_layer, styles, K, J);
+    if (K % 128 || J % 4) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * (128 * 64 + 16 * 128 + 128);
+    hipLaunchKernelGGL(dense_lds_kernel<true>, dim3((J + 63) / 64), dim3(256), lds, s, w, WT, b, styles, n, K, J, 0, avg, psi, col_layer);
     return hipGetLastError();
 }
 
