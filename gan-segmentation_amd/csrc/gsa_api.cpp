@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -376,7 +377,11 @@ struct Launch {
             unsigned long long h[16];
             (void)hipMemcpy(h, c->stamps, sizeof h, hipMemcpyDeviceToHost);
             (void)hipMemset(c->stamps, 0, sizeof h);
-            if (h[15]) {
+            if (h[15] && strstr(kname, "_ws")) {
+                const double w = (double)h[15];   // per wave (4 MFMA + 4 memory waves per workgroup)
+                fprintf(stderr, "STAMPWS %-24s %-16s waves %6llu  mfma: work %9.0f barrier %9.0f | mem: write %9.0f load %9.0f epi %9.0f barrier %9.0f\n",
+                        kname, label, h[15], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w);
+            } else if (h[15]) {
                 const double w = (double)h[15];
                 fprintf(stderr, "STAMP %-40s %-16s waves %8llu  load %7.0f  write %6.0f  bar %6.0f  blocks %8.0f  epi %7.0f\n", kname,
                         label, h[15], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w);
@@ -801,7 +806,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 if (!B.has_conv1) {
                     pp.src = c->constant; pp.src_per_sample = 0; pp.blur = nullptr;
                 } else {
-                    ConvParams cp{}; cp.stamps = c->stamps;
+                    ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0;
                     cp.src0 = c->x2[l - 1]; cp.aff0 = c->aff2[l - 1]; cp.C0 = Cin;
                     cp.Hs = R / 2; cp.Ws = R / 2; cp.H = R; cp.W = R;
                     cp.wpk = B.w1; cp.Cout = C; cp.out = c->t_raw;
@@ -825,15 +830,16 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 HIP_TRY(launch_post(pp, n, s));
                 prow = post_prow(R, R, C);
             } else {
-                ConvParams cp{}; cp.stamps = c->stamps;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0;
                 cp.src0 = c->x1; cp.aff0 = c->aff1; cp.C0 = C;
                 cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
                 cp.wpk = B.w2; cp.Cout = C; cp.out = c->x2[l];
-                cp.noise = nz; cp.nscale = B.nscale[1]; cp.nbias = B.nbias[1]; cp.partials = c->partials;
+                cp.noise = nz; cp.nscale = B.nscale[1]; cp.nbias = B.nbias[1]; cp.partials = c->partials; cp.acc = c->stat_acc;
                 snprintf(layer, sizeof layer, "g.%d.conv_2", R);
-                Launch lp(c, s, conv_kernel_name(R, C, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
+                const bool ws = conv_uses_ws(cp, EPI_SYNTH, false, n);
+                Launch lp(c, s, ws ? "conv3x3_ws<synth>" : conv_kernel_name(R, C, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
-                prow = conv_stat_rows(R, R, C, n);
+                prow = ws ? 0 : conv_stat_rows(R, R, C, n);
             }
             FinalizeParams fp{};
             fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C; fp.acc = c->stat_acc; fp.tickets = c->stat_tickets;
@@ -870,20 +876,20 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
         const int R = 4 << i;
         const double px = N * R * R;
         {   // cvt_block: conv3x3+bias -> BN -> LeakyReLU (Dropout is identity at inference)
-            ConvParams cp{}; cp.stamps = c->stamps;
+            ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0;
             cp.src0 = fsrc[i]; cp.aff0 = faff ? faff[i] : nullptr; cp.C0 = d.I;
             cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
             cp.wpk = d.cvt_w; cp.Cout = d.F; cp.out = c->cvt[i];
             cp.bias = d.cvt_b; cp.bn_s = d.cvt_s; cp.bn_rm = d.cvt_rm; cp.bn_beta = d.cvt_beta;
             snprintf(layer, sizeof layer, "d.cvt_%d", i);
-            Launch lp(c, s, conv_kernel_name(R, d.F, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
+            Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "conv3x3_ws<dec>" : conv_kernel_name(R, d.F, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
             HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
         }
         if (!d.is_last) {
             const int R2 = 2 * R;
             const double px2 = 4 * px;
             {   // ResBlock conv a (+ fused 1x1 shortcut) on nearest-x2(concat(prev, cvt))
-                ConvParams cp{}; cp.stamps = c->stamps;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0;
                 if (i > 0) { cp.src0 = c->prev[i - 1]; cp.C0 = d.F; cp.src1 = c->cvt[i]; cp.C1 = d.F; }
                 else { cp.src0 = c->cvt[i]; cp.C0 = d.F; }
                 cp.Hs = R; cp.Ws = R; cp.up = 1; cp.H = R2; cp.W = R2;
@@ -905,7 +911,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 }
             }
             {   // ResBlock conv b, + shortcut
-                ConvParams cp{}; cp.stamps = c->stamps;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0;
                 cp.src0 = c->ya[i]; cp.C0 = d.cs;
                 cp.Hs = R2; cp.Ws = R2; cp.H = R2; cp.W = R2;
                 cp.wpk = d.b_w; cp.Cout = d.cs; cp.out = c->prev[i];
@@ -913,7 +919,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = 0; }
                 else { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
-                Launch lp(c, s, conv_kernel_name(R2, d.cs, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
+                Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "conv3x3_ws<dec>" : conv_kernel_name(R2, d.cs, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
             }
         } else {

@@ -31,6 +31,7 @@ struct ConvParams {
     // EPI_SYNTH: AddNoise -> Bias -> LeakyReLU -> statistics
     const float* noise; const float* nscale; const float* nbias;
     StatPart* partials; int prow;      // prow = partial rows per sample
+    StatPart* acc;                     // wave-specialised kernel: statistics go straight to the accumulators
     // EPI_DEC: conv bias -> BatchNorm(inference) -> LeakyReLU [-> + resid]
     const float* bias; const float* bn_s; const float* bn_rm; const float* bn_beta;
     const float* resid; int resid_up;   // resid_up: residual lives at half resolution (identity shortcut)
@@ -38,6 +39,7 @@ struct ConvParams {
     const float* wsc; const float* sc_bias; float* out_sc;
     int tiles_x, tiles_y, groups, total_tiles;   // filled by the launcher
     unsigned long long* stamps;   // diagnostic build (-DGSA_STAMP) only: per-phase cycle sums
+    int dbg;                      // diagnostic build only: bit0 = stage pixel 0 everywhere (timing of a cache-resident input)
 };
 
 struct PostParams {
@@ -60,6 +62,7 @@ struct FinalizeParams {
 
 // launches (all stream-ordered, no sync)
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);
+bool conv_uses_ws(const ConvParams& p, int epi, bool shortcut, int n);   // true: wave-specialised kernel, no partial rows
 hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);   // deconv4x4s2 / sub-pixel up+conv3x3
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s);
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);

@@ -23,6 +23,7 @@
 #include "gsa_kernels.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 namespace gsa {
 
@@ -34,7 +35,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define STAMP_DECL unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP_FLUSH(nph) do { if (p.stamps && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < (nph); ++i_) atomicAdd(&p.stamps[i_], stamp_t[i_ + 1] - stamp_t[i_]); atomicAdd(&p.stamps[15], 1ull); } } while (0)
+#define TICK(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TSUM(acc, a, b) acc += (b) - (a)
+#define TFLUSH(idx, acc) do { if (p.stamps && (threadIdx.x & 63) == 0) atomicAdd(&p.stamps[idx], acc); } while (0)
 #else
+#define TICK(var) do {} while (0)
+#define TSUM(acc, a, b) do {} while (0)
+#define TFLUSH(idx, acc) do {} while (0)
 #define STAMP(i) do {} while (0)
 #define STAMP_DECL do {} while (0)
 #define STAMP_FLUSH(nph) do {} while (0)
@@ -47,6 +54,12 @@ __device__ __forceinline__ unsigned long long to_fixed(float v, double scale) {
     const double magic = 6755399441055744.0;
     double t = fma((double)v, scale, magic);
     return (unsigned long long)__double_as_longlong(t) - (unsigned long long)__double_as_longlong(magic);
+}
+
+// value of another lane of the same aligned quad (DPP quad_perm, no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
                             v[r] = lrelu((v[r] + t) + e1[nt]);
                         }
                         const float s = (v[0] + v[1]) + (v[2] + v[3]);
-                        const float q = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                        const float q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                         I1 += to_fixed(s, kStatScale1);
                         I2 += to_fixed(q, kStatScale2);
                     }
@@ -423,6 +436,345 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
 #endif
     STAMP(5);                                      // [4,5): last stores retired
     STAMP_FLUSH(5);
+}
+
+// ------------------------------------------------------------------------------------------
+// conv3x3, WAVE-SPECIALISED form for the layers whose tiles are short (few 16-channel blocks):
+// 8 waves per workgroup, one workgroup per CU.  Waves 0-3 (one per SIMD) only read LDS and
+// issue MFMAs; waves 4-7 are the memory side: they prefetch the (tile, block) item two steps
+// ahead from HBM, apply AdaIN, write the LDS images one step ahead (double buffered), and run
+// the epilogue of finished tiles out of an LDS copy of the accumulators -- noise/bias/
+// LeakyReLU/statistics or bias/BN/LeakyReLU/residual, then 16-B stores that cover whole rows.
+// The MFMA waves never touch global memory, so no vmcnt wait ever sits in front of an MFMA;
+// the two sides meet at one s_barrier per item.  (Stamps of the one-workgroup-per-tile kernel
+// showed the load, MFMA and store phases of a whole generation of workgroups in lockstep.)
+// Statistics leave through per-wave shuffles and device-scope 64-bit atomics straight into the
+// accumulators finalize_kernel consumes (no partial rows).
+constexpr int kWsLoaderWaves = 8;   // memory-side waves per workgroup (two per SIMD)
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(256 + 64 * kWsLoaderWaves) void conv3x3_ws(ConvParams p) {
+    constexpr int LT = 64 * kWsLoaderWaves;      // memory-side threads
+    constexpr int TH = 16, TW = 16, LH = 18, LW = 18, RS = LW * 16 + 8;
+    constexpr int Q = NT, COUT_T = 16 * Q, SEG = 9 * 256, NB4 = Q * SEG / 4;
+    constexpr int AIT = (LH * LW + LT - 1) / LT, BIT = (NB4 + LT - 1) / LT, FIT = (512 + LT - 1) / LT;   // FIT: AdaIN table <= 512 channels
+    constexpr int QL = 4 * Q;                    // channel quads per pixel = lanes per pixel in the epilogue
+    constexpr int EIT = 256 * QL / LT;           // epilogue passes: 256 px * QL quads / LT threads
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                            // [2][LH*RS]
+    float* sB = sA + 2 * LH * RS;                // [2][Q*SEG]
+    float* sOut = sB + 2 * Q * SEG;              // [2][256*COUT_T]  accumulators of a finished tile, [px][c]
+    f32x4* sAff = reinterpret_cast<f32x4*>(sOut + 2 * 256 * COUT_T);   // [2][C0] by sample parity
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mfma_wave = wave < 4;
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    const int chunk = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int w_begin = blockIdx.x * chunk;
+    const int w_end = min(p.total_tiles, w_begin + chunk);
+    if (w_begin >= w_end) return;
+    const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4;
+    const int total = (w_end - w_begin) * nblk;  // items of this workgroup
+    const bool has_aff = p.aff0 != nullptr;
+
+    if (mfma_wave) {
+        // =========================== MFMA side ===========================
+        const int wm = wave;
+        int abase[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) abase[mt] = (wm * 4 + (i16 >> 2)) * RS + (mt * 4 + (i16 & 3)) * 16 + kq * 4;
+        const int bbase = (kq * 16 + i16) * 4;
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                   // B0: AdaIN tables written
+        __syncthreads();                                   // B1: item 0 staged
+        int tcount = 0;
+        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, ts_work = 0, ts_bar = 0;
+        (void)tk0; (void)tk1; (void)tk2; (void)ts_work; (void)ts_bar;
+        for (int i = 0; i <= total; ++i) {
+            TICK(tk0);
+#ifdef GSA_STAMP
+            if (p.dbg & 2) { TICK(tk1); __syncthreads(); TICK(tk2); continue; }   // timing-only: idle MFMA side
+#endif
+            if (i < total) {
+                const float* a_img = sA + (i & 1) * (LH * RS);
+                const float* b_img = sB + (i & 1) * (Q * SEG);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int toff = (tap / 3) * RS + (tap % 3) * 16;
+                    f32x4 a[4], b[NT];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_img + abase[mt] + toff);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(b_img + bbase + nt * SEG + tap * 256);
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
+                }
+                if (i % nblk == nblk - 1) {
+                    // tile finished: hand the accumulators to the memory side, [px][channel]
+                    float* o = sOut + (tcount & 1) * (256 * COUT_T);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                o[((wm * 4 + (lane >> 4)) * TW + mt * 4 + r) * COUT_T + nt * 16 + i16] = acc[mt][nt][r];
+                            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    ++tcount;
+                }
+            }
+            TICK(tk1);
+            __syncthreads();
+            TICK(tk2);
+            TSUM(ts_work, tk0, tk1); TSUM(ts_bar, tk1, tk2);
+        }
+        TFLUSH(0, ts_work); TFLUSH(1, ts_bar);
+#ifdef GSA_STAMP
+        if (p.stamps && lane == 0) atomicAdd(&p.stamps[15], 1ull);
+#endif
+        return;
+    }
+
+    // =========================== memory side (waves 4-7) ===========================
+    const int ltid = tid - 256;
+    auto decode = [&](int w) {
+        WorkTile t;
+        const int tx = w % p.tiles_x;
+        int r = w / p.tiles_x;
+        const int ty = r % p.tiles_y;
+        r /= p.tiles_y;
+        t.g = r % p.groups;
+        t.n = r / p.groups;
+        t.y0 = ty * TH; t.x0 = tx * TW;
+        t.row = ty * p.tiles_x + tx;
+        return t;
+    };
+    auto item_tile = [&](int i) { return decode(w_begin + min(i, total - 1) / nblk); };
+    auto tile_pixels = [&](const WorkTile& t, TilePixel (&tp)[AIT]) {
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const int idx = ltid + it * LT;
+            const int ly = idx / LW, lx = idx % LW;
+            const int gy = t.y0 - 1 + ly, gx = t.x0 - 1 + lx;
+            const bool stage = idx < LH * LW;
+            const bool inside = stage && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            tp[it].lds = stage ? ly * RS + lx * 16 : -1;
+            tp[it].pix = inside ? (t.n * p.Hs + gy) * p.Ws + gx : -1;
+#ifdef GSA_STAMP
+            if ((p.dbg & 1) && inside) tp[it].pix = lx & 1;      // timing-only: every load hits the same two pixels
+#endif
+        }
+    };
+    // D-deep register ring of prefetched items: with one workgroup per CU the bytes in flight
+    // per CU are what the prefetch depth makes them (Little's law: ~30 KB per item, HBM latency
+    // of several microseconds under load), so one item ahead is not enough
+    constexpr int D = 3;
+    f32x4 ra[D][AIT][4], rb[D][BIT];
+    TilePixel tps[D][AIT];
+    WorkTile tws[D];
+    auto load_item = [&](int i, f32x4 (&a)[AIT][4], f32x4 (&b)[BIT], TilePixel (&tp)[AIT], WorkTile& t) {
+        t = item_tile(i);
+        tile_pixels(t, tp);
+        const int cb = min(i, total - 1) % nblk;
+        const bool first = cb < nblk0;
+        const float* src = first ? p.src0 : p.src1;
+        const int Cs = first ? p.C0 : p.C1;
+        const int coff = (first ? cb : cb - nblk0) * 16;
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) load_pixel(a[it], src, Cs, coff, tp[it]);
+#pragma unroll
+        for (int j = 0; j < BIT; ++j) {
+            const int k = min(ltid + j * LT, NB4 - 1);
+            const int q = k / (SEG / 4), r = k % (SEG / 4);
+            b[j] = reinterpret_cast<const f32x4*>(p.wpk + ((size_t)(t.g * Q + q) * nblk + cb) * SEG)[r];
+        }
+    };
+    auto copy_aff = [&](int n) {     // AdaIN table of sample n -> sAff[n & 1]
+#pragma unroll
+        for (int j = 0; j < FIT; ++j) {
+            const int k = min(ltid + j * LT, p.C0 - 1);
+            sAff[(n & 1) * p.C0 + k] = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)n * p.C0)[k];
+        }
+    };
+    auto write_item = [&](int i, f32x4 (&a)[AIT][4], f32x4 (&b)[BIT], const TilePixel (&tp)[AIT], const WorkTile& t) {
+        const int cb = i % nblk;
+        float* a_img = sA + (i & 1) * (LH * RS);
+        if (cb < nblk0 && has_aff) {
+            const float4* tab = reinterpret_cast<const float4*>(sAff + (t.n & 1) * p.C0) + cb * 16;
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) store_pixel<true>(a_img, a[it], tab, tp[it]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) store_pixel<false>(a_img, a[it], reinterpret_cast<const float4*>(sAff), tp[it]);
+        }
+        f32x4* b_img = reinterpret_cast<f32x4*>(sB + (i & 1) * (Q * SEG));
+#pragma unroll
+        for (int j = 0; j < BIT; ++j) b_img[min(ltid + j * LT, NB4 - 1)] = b[j];
+    };
+
+    // epilogue mapping: lane bits [0:1] = x & 3 (so an x-quad sits in 4 adjacent lanes and is
+    // summed with DPP quad permutes), next log2(QL) bits = channel quad, the rest = pixel group:
+    // pass k covers pixel groups k*GPP + rem, group pg -> row pg>>2, columns 4*(pg&3)..+3.
+    // A wave still writes whole rows: 16 pixels x 64 B (or 8 x 128 B) contiguous.
+    const int xl = ltid & 3, equad = (ltid >> 2) % QL, erem = (ltid >> 2) / QL;
+    constexpr int GPP = LT / 4 / QL;             // pixel groups per pass
+    unsigned long long st1 = 0, st2 = 0;         // running statistics of channel 4*equad + xl of this thread
+    int stat_n = -1, stat_g = 0;
+    auto flush_stats = [&]() {
+        if (EPI != EPI_SYNTH || stat_n < 0) return;
+        // lanes that share (xl, equad) are 4*QL apart: fold them, then one atomic pair per channel and wave
+#pragma unroll
+        for (int m = 4 * QL; m < 64; m <<= 1) {
+            st1 += shfl_xor_u64(st1, m);
+            st2 += shfl_xor_u64(st2, m);
+        }
+        if (lane < 4 * QL) {
+            StatPart* a = p.acc + (size_t)stat_n * p.Cout + stat_g * COUT_T + equad * 4 + xl;
+            atomicAdd(&a->s1, st1);
+            atomicAdd(&a->s2, st2);
+        }
+        st1 = 0; st2 = 0;
+    };
+
+    // ---- prologue: ring set j % D holds item j
+    load_item(0, ra[0], rb[0], tps[0], tws[0]);
+    int aff_n = tws[0].n;             // newest sample whose AdaIN table is in sAff
+    if (has_aff) copy_aff(aff_n);
+    __syncthreads();                                       // B0
+    write_item(0, ra[0], rb[0], tps[0], tws[0]);
+#pragma unroll
+    for (int j = 1; j <= D; ++j) {
+        load_item(j, ra[j % D], rb[j % D], tps[j % D], tws[j % D]);
+        if (has_aff && tws[j % D].n != aff_n) { aff_n = tws[j % D].n; copy_aff(aff_n); }
+    }
+    __syncthreads();                                       // B1
+
+    // epilogue inputs (noise / residual) are prefetched one iteration ahead, the per-channel
+    // constants are reloaded only when the channel group changes
+    float nzv[EPI == EPI_SYNTH ? EIT : 1];
+    f32x4 rr[EPI == EPI_DEC ? EIT : 1];
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+    int const_g = -1;
+    const bool has_resid = EPI == EPI_DEC && p.resid != nullptr;
+    auto prefetch_epilogue = [&](const WorkTile& t) {
+        const int co = t.g * COUT_T + equad * 4;
+        if (EPI == EPI_SYNTH) {
+#pragma unroll
+            for (int k = 0; k < EIT; ++k) {
+                const int pg = k * GPP + erem;
+                nzv[k] = p.noise[(size_t)(t.n * p.H + t.y0 + (pg >> 2)) * p.W + t.x0 + (pg & 3) * 4 + xl];
+            }
+        }
+        if (EPI == EPI_DEC && has_resid) {
+#pragma unroll
+            for (int k = 0; k < EIT; ++k) {
+                const int pg = k * GPP + erem;
+                const int y = t.y0 + (pg >> 2), x = t.x0 + (pg & 3) * 4 + xl;
+                const size_t rp = p.resid_up ? (size_t)(t.n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1)
+                                             : (size_t)(t.n * p.H + y) * p.W + x;
+                rr[k] = *reinterpret_cast<const f32x4*>(p.resid + rp * p.Cout + co);
+            }
+        }
+    };
+
+    unsigned long long lk0 = 0, lk1 = 0, lk2 = 0, lk3 = 0, lk4 = 0, ls_w = 0, ls_l = 0, ls_e = 0, ls_b = 0;
+    (void)lk0; (void)lk1; (void)lk2; (void)lk3; (void)lk4; (void)ls_w; (void)ls_l; (void)ls_e; (void)ls_b;
+    for (int i0 = 0; i0 <= total; i0 += D) {
+#pragma unroll
+      for (int ph = 0; ph < D; ++ph) {
+        const int i = i0 + ph;
+        if (i > total) break;                 // wave-uniform; keeps the barrier count equal to the MFMA side
+        constexpr int kDummy = 0; (void)kDummy;
+        const int set = (ph + 1) % D;         // static: ring set of item i+1 (i0 is a multiple of D)
+        TICK(lk0);
+        // L1: stage item i+1 (its loads were issued D iterations ago)
+        if (i + 1 < total) write_item(i + 1, ra[set], rb[set], tps[set], tws[set]);
+        TICK(lk1);
+        // L3: prefetch item i+1+D into the ring set just freed
+        load_item(i + 1 + D, ra[set], rb[set], tps[set], tws[set]);
+        if (has_aff && i + 1 + D < total && tws[set].n != aff_n) { aff_n = tws[set].n; copy_aff(aff_n); }   // rare
+        TICK(lk2);
+        // the tile that finished in iteration i-1 (if any)
+        const bool have_epi = i >= 1 && (i - 1) % nblk == nblk - 1;
+        const WorkTile te = decode(w_begin + (max(i, 1) - 1) / nblk);
+        if (have_epi && te.g != const_g) {       // rare: per-channel constants of a new channel group
+            const int co = te.g * COUT_T + equad * 4;
+            if (EPI == EPI_SYNTH) {
+                c0 = *reinterpret_cast<const f32x4*>(p.nscale + co);
+                c1 = *reinterpret_cast<const f32x4*>(p.nbias + co);
+            }
+            if (EPI == EPI_DEC) {
+                c0 = *reinterpret_cast<const f32x4*>(p.bias + co);
+                c1 = *reinterpret_cast<const f32x4*>(p.bn_rm + co);
+                c2 = *reinterpret_cast<const f32x4*>(p.bn_s + co);
+                c3 = *reinterpret_cast<const f32x4*>(p.bn_beta + co);
+            }
+            const_g = te.g;
+        }
+        // L4: epilogue of the finished tile out of sOut
+        if (have_epi) {
+            if (EPI == EPI_SYNTH && (te.n != stat_n || te.g != stat_g)) { flush_stats(); stat_n = te.n; stat_g = te.g; }
+            const float* o = sOut + (((i - 1) / nblk) & 1) * (256 * COUT_T);
+            const int co = te.g * COUT_T + equad * 4;
+#pragma unroll
+            for (int k = 0; k < EIT; ++k) {
+                const int pg = k * GPP + erem;
+                const int yl = pg >> 2, xt = (pg & 3) * 4 + xl;
+                const int y = te.y0 + yl, x = te.x0 + xt;
+                f32x4 v = *reinterpret_cast<const f32x4*>(o + (yl * TW + xt) * COUT_T + equad * 4);
+                if (EPI == EPI_SYNTH) {
+                    float s4 = 0.f, q4 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float t = c0[j] * nzv[k];
+                        v[j] = lrelu((v[j] + t) + c1[j]);
+                        // x-quad = 4 adjacent lanes: (v0+v1)+(v2+v3) via quad_perm [1,0,3,2] then [2,3,0,1];
+                        // commutativity makes the result the same bits in all four lanes
+                        const float sq = v[j] * v[j];
+                        const float t1 = v[j] + dpp_quad<0xB1>(v[j]);
+                        const float u1 = sq + dpp_quad<0xB1>(sq);
+                        const float t2 = t1 + dpp_quad<0x4E>(t1);
+                        const float u2 = u1 + dpp_quad<0x4E>(u1);
+                        if (j == 0) { s4 = t2; q4 = u2; }
+                        else { s4 = xl == j ? t2 : s4; q4 = xl == j ? u2 : q4; }   // lane xl keeps channel 4*equad+xl
+                    }
+                    st1 += to_fixed(s4, kStatScale1);
+                    st2 += to_fixed(q4, kStatScale2);
+                }
+                if (EPI == EPI_DEC) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float yv = v[j] + c0[j];
+                        v[j] = lrelu(fmaf(yv - c1[j], c2[j], c3[j]));
+                        if (has_resid) v[j] = rr[k][j] + v[j];
+                    }
+                }
+                *reinterpret_cast<f32x4*>(p.out + ((size_t)(te.n * p.H + y) * p.W + x) * p.Cout + co) = v;
+            }
+        }
+        // inputs of the NEXT epilogue: the tile whose last block is item i finishes in this iteration
+        // and is consumed in iteration i+1, i.e. these loads have a whole iteration to land
+        if (i < total && i % nblk == nblk - 1) prefetch_epilogue(item_tile(i));
+        TICK(lk3);
+        __syncthreads();
+        TICK(lk4);
+        TSUM(ls_w, lk0, lk1); TSUM(ls_l, lk1, lk2); TSUM(ls_e, lk2, lk3); TSUM(ls_b, lk3, lk4);
+      }
+    }
+    TFLUSH(2, ls_w); TFLUSH(3, ls_l); TFLUSH(4, ls_e); TFLUSH(5, ls_b);
+    flush_stats();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -670,7 +1022,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float s = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
-            const float q = fmaf(v[3][j], v[3][j], fmaf(v[2][j], v[2][j], fmaf(v[1][j], v[1][j], v[0][j] * v[0][j])));
+            const float q = (v[0][j] * v[0][j] + v[1][j] * v[1][j]) + (v[2][j] * v[2][j] + v[3][j] * v[3][j]);
             atomicAdd(&sstat[c + j], to_fixed(s, kStatScale1));
             atomicAdd(&sstat[p.C + c + j], to_fixed(q, kStatScale2));
         }
@@ -750,17 +1102,20 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p, int row
 // ------------------------------------------------------------------------------------------
 // Mapping network pieces.  Every output is one k-ordered fmaf chain (canonical order).
 __global__ void pixelnorm_kernel(const float* z, float* out, int n, int L) {
-    // one wave per sample: lane 0 runs the chain, all lanes scale
+    // one wave per sample: the row goes to LDS, lane 0 runs the canonical chain, all lanes scale
+    extern __shared__ __attribute__((aligned(16))) float srow[];
+    __shared__ float rn;
     const int s = blockIdx.x;
     const float* zs = z + (size_t)s * L;
-    __shared__ float rn;
+    for (int k = threadIdx.x; k < L; k += blockDim.x) srow[k] = zs[k];
+    __syncthreads();
     if (threadIdx.x == 0) {
         float ss = 0.0f;
-        for (int k = 0; k < L; ++k) ss = fmaf(zs[k], zs[k], ss);
+        for (int k = 0; k < L; ++k) ss = fmaf(srow[k], srow[k], ss);
         rn = 1.0f / sqrtf(ss / (float)L + 1e-8f);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < L; k += blockDim.x) out[(size_t)s * L + k] = zs[k] * rn;
+    for (int k = threadIdx.x; k < L; k += blockDim.x) out[(size_t)s * L + k] = srow[k] * rn;
 }
 
 // Dense layer(s) with the weight panel staged through LDS: one workgroup = 64 output columns
@@ -1010,7 +1365,7 @@ static ConvGeom pick_geom(int H, int W, int Cout, int n) {
     return best;
 }
 
-int conv_stat_rows(int H, int W, int Cout, int n) {
+int conv_stat_rows(int H, int W, int Cout, int n) {   // rows of the non-specialised kernel (upper bound for the workspace)
     const ConvGeom c = pick_geom(H, W, Cout, n);
     return (H / c.th) * (W / c.th) * c.wm;
 }
@@ -1073,8 +1428,59 @@ static hipError_t launch_conv_e(const ConvParams& p, int epi, bool sc, int n, hi
     return hipErrorInvalidValue;
 }
 
+template <int NT, int EPI>
+static hipError_t launch_conv_ws_t(const ConvParams& p, int n, hipStream_t s) {
+    constexpr int Q = NT, COUT_T = 16 * Q;
+    const size_t lds = sizeof(float) * (2 * 18 * (18 * 16 + 8) + 2 * Q * 9 * 256 + 2 * 256 * COUT_T) + (p.aff0 ? 2 * sizeof(float4) * p.C0 : 0);
+    auto kern = conv3x3_ws<NT, EPI>;
+    static bool attr_done = false;
+    static int num_cus = 0;
+    if (!attr_done) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    ConvParams q = p;
+    q.tiles_x = p.W / 16;
+    q.tiles_y = p.H / 16;
+    q.groups = p.Cout / COUT_T;
+    q.prow = 0;
+    q.total_tiles = q.tiles_x * q.tiles_y * q.groups * n;
+    const int grid = q.total_tiles < num_cus ? q.total_tiles : num_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + 64 * kWsLoaderWaves), lds, s, q);
+    return hipGetLastError();
+}
+
+// The wave-specialised kernel is used where tiles are short and plentiful.
+bool conv_uses_ws(const ConvParams& p, int epi, bool sc, int n) {
+    // EXPERIMENTAL, off by default (GSA_WS=1 enables): measured slower than the one-workgroup-per-tile
+    // kernel on MI355X -- with K = 144 per output the memory side's VALU/LDS work per item equals the
+    // MFMA time and the two sides contend for the SIMD's issue slots (stamps in DESIGN.md section 4).
+    static const bool enabled = getenv("GSA_WS") && atoi(getenv("GSA_WS")) != 0;
+    if (!enabled) return false;
+    if (sc || epi == EPI_RAW || p.up || p.H < 64) return false;
+    if (p.Cout % 16 || p.Cout > 32) return false;                  // NT 1 or 2 with COUT_T == Cout
+    if ((p.C0 + p.C1) > 64 || (p.aff0 && p.C0 > 512)) return false;
+    const long tiles = (long)(p.H / 16) * (p.W / 16) * n;
+    return tiles >= 1024;   // (H >= 64: >= 16 tiles per sample, more than the prefetch depth -- see the AdaIN table parity)
+}
+
+hipError_t launch_conv3x3_ws(const ConvParams& p, int epi, int n, hipStream_t s) {
+    const int nt = p.Cout / 16;
+    if (nt == 1 && epi == EPI_SYNTH) return launch_conv_ws_t<1, EPI_SYNTH>(p, n, s);
+    if (nt == 1 && epi == EPI_DEC) return launch_conv_ws_t<1, EPI_DEC>(p, n, s);
+    if (nt == 2 && epi == EPI_SYNTH) return launch_conv_ws_t<2, EPI_SYNTH>(p, n, s);
+    if (nt == 2 && epi == EPI_DEC) return launch_conv_ws_t<2, EPI_DEC>(p, n, s);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     if (p.H != p.W || (p.H & (p.H - 1)) || p.H < 4 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
+    if (conv_uses_ws(p, epi, sc, n)) return launch_conv3x3_ws(p, epi, n, s);
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
 #define GSA_GEOM(TH, WM, WN, NT) \
     if (c.th == TH && c.wm == WM && c.wn == WN && c.nt == NT) return launch_conv_e<TH, TH, WM, WN, NT>(p, epi, sc, n, s);
@@ -1145,13 +1551,14 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
 
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s) {
     const int rpb = 256;
-    dim3 grid((p.C + 63) / 64, n, (p.prow + rpb - 1) / rpb);
+    const int zb = (p.prow + rpb - 1) / rpb;   // prow == 0: the producer already summed into acc
+    dim3 grid((p.C + 63) / 64, n, zb < 1 ? 1 : zb);
     hipLaunchKernelGGL(finalize_kernel, grid, dim3(256), 0, s, p, rpb);
     return hipGetLastError();
 }
 
 hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_t s) {
-    hipLaunchKernelGGL(pixelnorm_kernel, dim3(n), dim3(64), 0, s, z, out, n, L);
+    hipLaunchKernelGGL(pixelnorm_kernel, dim3(n), dim3(64), sizeof(float) * L, s, z, out, n, L);
     return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@
  *          (channels in blocks of 16, the taps inside a block; out-of-image taps skipped,
  *          which equals adding +0; 1x1 convs and dense layers are plain k-ordered chains)
  *   stats  per (n,c), per aligned quad of 4 consecutive x:
- *          s=(v0+v1)+(v2+v3), q=fmaf(v3,v3,fmaf(v2,v2,fmaf(v1,v1,v0*v0)));
+ *          s=(v0+v1)+(v2+v3), q=(v0*v0+v1*v1)+(v2*v2+v3*v3) (every product and sum rounded);
  *          I1 += rint(s*2^28), I2 += rint(q*2^20) as wrapping 64-bit integers
  *          (order independent, hence tiling independent)
  *   AdaIN  out = fmaf(x - mean, A, B) with A,B from finalize() below
@@ -453,7 +453,7 @@ static void plane_stats(const float* x, int H, int W, int C, uint64_t* I1, uint6
             for (int c = 0; c < C; ++c) {
                 float v0 = p[c], v1 = p[C + c], v2 = p[2 * C + c], v3 = p[3 * C + c];
                 float s = (v0 + v1) + (v2 + v3);
-                float q = fmaf(v3, v3, fmaf(v2, v2, fmaf(v1, v1, v0 * v0)));
+                float q = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
                 I1[c] += to_fixed(s, STAT_SCALE1);
                 I2[c] += to_fixed(q, STAT_SCALE2);
             }
