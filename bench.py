@@ -25,6 +25,23 @@ PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_summary.json, produced by tools_pmc.sh + tools_pmc_report.py: separate
+    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if absent."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            with open(path) as f:
+                for k in json.load(f)["kernels"]:
+                    if k["kernel"] == kernel_name:
+                        best = {"bytes_per_launch": round(k["hbm_bytes_per_launch"]), "source": os.path.basename(path)}
+        except (OSError, ValueError, KeyError):
+            pass
+    return best
+
+
 def host_cores():
     """Threads this process may really use: CPU affinity capped by the cgroup CPU quota; on a
     shared GPU box that reports neither, the documented one-GPU CPU share (16)."""
@@ -154,10 +171,15 @@ def main():
         top = entries[0]
         kms = sum(e["ms"] for e in entries)
         ach = top["flops"] / (top["ms"] * 1e-3) / 1e12 if top["ms"] > 0 else 0.0
+        tr = pmc_traffic(top["name"])
         roofline = {"bound": "mfma", "kernel": top["name"], "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
                     "avg_launch_ms": round(top["ms"] / max(1, top["launches"]), 4),
-                    "launches": top["launches"], "traffic": None}
+                    "launches": top["launches"],
+                    "flops_per_launch": round(top["flops"] / max(1, top["launches"])),
+                    "algorithmic_bytes_per_launch": round(top["bytes"] / max(1, top["launches"])),
+                    "traffic": tr["bytes_per_launch"] if tr else None,
+                    "traffic_source": tr["source"] if tr else None}
         out = {
             "metric": "synthetic (image,mask) pairs/sec, %s-%d StyleGAN+decoder" % (args.gan.upper(), 2 ** mr),
             "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,

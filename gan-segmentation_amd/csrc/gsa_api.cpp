@@ -396,8 +396,8 @@ struct Launch {
 
 const char* conv_kernel_name(int H, int Cout, int n, int epi, bool sc) {
     static thread_local char buf[96];
-    snprintf(buf, sizeof buf, "conv3x3_mfma<%s,%s%s>", conv_geom_name(H, H, Cout, n),
-             epi == EPI_RAW ? "raw" : (epi == EPI_SYNTH ? "synth" : "dec"), sc ? "+sc" : "");
+    snprintf(buf, sizeof buf, "void gsa::conv3x3_mfma<%s, %d, %s>(gsa::ConvParams)", conv_geom_name(H, H, Cout, n), epi,
+             sc ? "true" : "false");
     return buf;
 }
 
@@ -813,8 +813,8 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                     if (B.is_deconv || R >= 16) {
                         // Deconvolution 4x4 s2, or nearest-x2 + conv3x3 in sub-pixel form (same kernel)
                         snprintf(layer, sizeof layer, B.is_deconv ? "g.%d.deconv_1" : "g.%d.conv_1", R);
-                        static thread_local char kn[64];
-                        snprintf(kn, sizeof kn, "subpixel_mfma<%s,raw>", subpixel_geom_name(R, R, C, n));
+                        static thread_local char kn[96];
+                        snprintf(kn, sizeof kn, "void gsa::subpixel_mfma<%s, 0, false>(gsa::ConvParams)", subpixel_geom_name(R, R, C, n));
                         Launch lp(c, s, kn, layer, 2.0 * px * C * Cin * 4, 4.0 * (px / 4 * Cin + px * C));
                         HIP_TRY(launch_subpixel(cp, EPI_RAW, false, n, s));
                     } else {
@@ -837,7 +837,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 cp.noise = nz; cp.nscale = B.nscale[1]; cp.nbias = B.nbias[1]; cp.partials = c->partials; cp.acc = c->stat_acc;
                 snprintf(layer, sizeof layer, "g.%d.conv_2", R);
                 const bool ws = conv_uses_ws(cp, EPI_SYNTH, false, n);
-                Launch lp(c, s, ws ? "conv3x3_ws<synth>" : conv_kernel_name(R, C, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
+                Launch lp(c, s, ws ? "void gsa::conv3x3_ws<ws, 1>(gsa::ConvParams)" : conv_kernel_name(R, C, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
                 prow = ws ? 0 : conv_stat_rows(R, R, C, n);
             }
@@ -882,7 +882,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             cp.wpk = d.cvt_w; cp.Cout = d.F; cp.out = c->cvt[i];
             cp.bias = d.cvt_b; cp.bn_s = d.cvt_s; cp.bn_rm = d.cvt_rm; cp.bn_beta = d.cvt_beta;
             snprintf(layer, sizeof layer, "d.cvt_%d", i);
-            Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "conv3x3_ws<dec>" : conv_kernel_name(R, d.F, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
+            Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(R, d.F, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
             HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
         }
         if (!d.is_last) {
@@ -898,8 +898,8 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 if (d.has_sc) { cp.wsc = d.sc_w; cp.sc_bias = d.sc_b; cp.out_sc = c->scb[i]; }
                 snprintf(layer, sizeof layer, "d.main_%d.a", i);
                 if (R2 >= 16) {   // sub-pixel form: 4 taps per output instead of 9
-                    static thread_local char kn[64];
-                    snprintf(kn, sizeof kn, "subpixel_mfma<%s,dec%s>", subpixel_geom_name(R2, R2, d.cs, n), d.has_sc ? "+sc" : "");
+                    static thread_local char kn[96];
+                    snprintf(kn, sizeof kn, "void gsa::subpixel_mfma<%s, 2, %s>(gsa::ConvParams)", subpixel_geom_name(R2, R2, d.cs, n), d.has_sc ? "true" : "false");
                     Launch lp(c, s, kn, layer, 2.0 * px2 * d.cs * d.in_c * (4 + (d.has_sc ? 1 : 0)),
                               4.0 * (px * d.in_c + px2 * d.cs * (d.has_sc ? 2 : 1)));
                     cp.up = 0;
@@ -919,7 +919,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = 0; }
                 else { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
-                Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "conv3x3_ws<dec>" : conv_kernel_name(R2, d.cs, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
+                Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(R2, d.cs, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
             }
         } else {
