@@ -782,7 +782,7 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
             if (!d.is_last) {
                 if (int rc = dev_alloc(c, N * 4 * R * R * d.cs, &c->ya[i], T)) return rc;
                 if (int rc = dev_alloc(c, N * 4 * R * R * d.cs, &c->prev[i], T)) return rc;
-                if (d.has_sc)
+                if (d.has_sc)   // shortcut at the INPUT resolution when the sub-pixel kernel produces it
                     if (int rc = dev_alloc(c, N * 4 * R * R * d.cs, &c->scb[i], T)) return rc;
             }
         }
@@ -922,8 +922,8 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 if (R2 >= 16) {   // sub-pixel form: 4 taps per output instead of 9
                     static thread_local char kn[96];
                     snprintf(kn, sizeof kn, "void gsa::subpixel_mfma<%s, 2, %s>(gsa::ConvParams)", subpixel_geom_name(R2, R2, d.cs, n), d.has_sc ? "true" : "false");
-                    Launch lp(c, s, kn, layer, 2.0 * px2 * d.cs * d.in_c * (4 + (d.has_sc ? 1 : 0)),
-                              4.0 * (px * d.in_c + px2 * d.cs * (d.has_sc ? 2 : 1)));
+                    Launch lp(c, s, kn, layer, 2.0 * px2 * d.cs * d.in_c * 4 + (d.has_sc ? 2.0 * px * d.cs * d.in_c : 0.0),
+                              4.0 * (px * d.in_c + px2 * d.cs + (d.has_sc ? px * d.cs : 0.0)));
                     cp.up = 0;
                     HIP_TRY(launch_subpixel(cp, EPI_DEC, d.has_sc, n, s));
                 } else {
@@ -938,7 +938,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 cp.Hs = R2; cp.Ws = R2; cp.H = R2; cp.W = R2;
                 cp.wpk = d.b_w; cp.Cout = d.cs; cp.out = c->prev[i];
                 cp.bias = d.b_b; cp.bn_s = d.b_s; cp.bn_rm = d.b_rm; cp.bn_beta = d.b_beta;
-                if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = 0; }
+                if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = R2 >= 16 ? 1 : 0; }   // sub-pixel conv a stores the shortcut at input resolution
                 else { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
                 Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(R2, d.cs, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);

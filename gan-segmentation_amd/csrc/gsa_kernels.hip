@@ -815,15 +815,21 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
     for (int mt = 0; mt < 4; ++mt)
         abase[mt] = ((mt >> 1) * 4 + (i16 >> 2) + 1) * RS + ((mt & 1) * 4 + (i16 & 3) + 1) * 16 + kq * 4;
     const int bbase = (kq * 16 + i16) * 4;
+    // fused 1x1 shortcut: on a nearest-upsampled input it is the same value for the 4 sub-pixels of
+    // an input pixel, so it is computed ONCE per input pixel and stored at the input resolution
+    // (the consumer reads it with resid_up).  The 8x8 input pixels of the tile are 4 patches; wave w
+    // takes patch w (A operand = the offset-(0,0) tap of that patch).
+    const int asc = ((wave >> 1) * 4 + (i16 >> 2) + 1) * RS + ((wave & 1) * 4 + (i16 & 3) + 1) * 16 + kq * 4;
     f32x4 acc[4][NT];
-    f32x4 accs[SC ? 4 : 1][SC ? NT : 1];
+    f32x4 accs[SC ? NT : 1];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (SC) accs[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (SC) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4;
     f32x4 ra[4], rb[BIT], rs[SC ? SIT : 1];
@@ -893,21 +899,18 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
-                if (SC && jy == (py ? 1 : 0) && jx == (px ? 1 : 0)) {
-                    // 1x1 shortcut on the upsampled input = the tap with offset (0,0); both
-                    // conditions are wave-uniform (py, px come from the wave index)
-                    f32x4 bs[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bs[nt] = *reinterpret_cast<const f32x4*>(sS + bbase + nt * 256);
-#pragma unroll
-                    for (int cg = 0; cg < 4; ++cg)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                accs[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], bs[nt][cg], accs[mt][nt], 0, 0, 0);
-                }
             }
+        }
+        if (SC) {   // natural channel order: block, then 4 k-slots of 4 channels
+            const f32x4 as = *reinterpret_cast<const f32x4*>(sA + asc);
+            f32x4 bs[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bs[nt] = *reinterpret_cast<const f32x4*>(sS + bbase + nt * 256);
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    accs[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[cg], bs[nt][cg], accs[nt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (cb + 1 < nblk) {
@@ -940,7 +943,14 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
                     v = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
                 }
                 p.out[o] = v;
-                if (SC) p.out_sc[o] = accs[mt][nt][r] + scb[nt];
+            }
+        }
+        if (SC) {
+            const int iy = y0 / 2 + (wave >> 1) * 4 + (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ix = x0 / 2 + (wave & 1) * 4 + r;
+                p.out_sc[((size_t)(n * p.Hs + iy) * p.Ws + ix) * p.Cout + co] = accs[nt][r] + scb[nt];
             }
         }
     }
