@@ -18,7 +18,7 @@ HIP_LIBRARY = os.path.join(_HERE, "csrc", "libgsa_hip.so")
 API_SYMBOLS = (
     "create", "destroy", "last_error", "generator_init", "generator_set_param",
     "generator_commit", "decoder_init", "decoder_set_param", "decoder_commit", "reserve",
-    "generator_forward", "decoder_forward", "generate", "profile_enable", "profile_collect",
+    "generator_forward", "decoder_forward", "generate", "set_overlap", "profile_enable", "profile_collect",
     "profile_entry", "profile_reset", "version",
 )
 
@@ -66,6 +66,7 @@ class Api:
             "generator_forward": (c.c_int, [vp, vp, i32, vp, c.POINTER(vp), vp, vp, c.POINTER(vp)]),
             "decoder_forward": (c.c_int, [vp, vp, i32, c.POINTER(vp), vp, vp]),
             "generate": (c.c_int, [vp, vp, i32, vp, c.POINTER(vp), vp, vp]),
+            "set_overlap": (c.c_int, [vp, i32]),
             "profile_enable": (c.c_int, [vp, i32]),
             "profile_collect": (c.c_int, [vp]),
             "profile_entry": (c.c_int, [vp, i32, c.POINTER(c.c_char_p), c.POINTER(c.c_double),
@@ -192,6 +193,9 @@ class Context:
 
     def generate(self, stream, n, z, noise, img, mask):
         self._check(self.api.generate(self._h, stream, n, z, _ptr_array(noise), img, mask), "generate")
+
+    def set_overlap(self, levels):
+        self._check(self.api.set_overlap(self._h, int(levels)), "set_overlap")
 
     # -- measurement ----------------------------------------------------------------------
     def profile_enable(self, on=True):

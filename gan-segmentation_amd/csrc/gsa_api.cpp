@@ -1018,6 +1018,12 @@ int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const floa
     return run_decoder(c, s, n, fsrc, faff, nullptr, mask, ns, -1, false);
 }
 
+int gsa_set_overlap(gsa_ctx* c, int32_t levels) {
+    if (!c) return GSA_ERR_INVALID;
+    c->side_levels = levels < 0 ? 0 : levels;
+    return GSA_OK;
+}
+
 // ------------------------------------------------------------------------ measurement hooks
 
 int gsa_profile_enable(gsa_ctx* c, int32_t on) {

@@ -122,6 +122,12 @@ int gsa_decoder_forward(gsa_ctx* ctx, void* stream, int32_t n, const float* cons
 int gsa_generate(gsa_ctx* ctx, void* stream, int32_t n, const float* z,
                  const float* const* noise, uint8_t* img, uint8_t* mask);
 
+/* gsa_generate runs the decoder on a second HIP stream beside the synthesis of the higher
+ * resolutions (fork/join through events).  `levels` = number of decoder levels placed there
+ * (default: all but the last; 0 = everything on the caller's stream, used by bench.py's
+ * serialized roofline pass so that kernel durations are not stretched by concurrent kernels). */
+int gsa_set_overlap(gsa_ctx* ctx, int32_t levels);
+
 /* --- measurement hooks (bench.py) ------------------------------------------------------ */
 
 /* When enabled every kernel launch is bracketed by hipEvents on the launch stream. */

@@ -152,7 +152,7 @@ def test_error_paths(torch_cuda):
         ctx.generator_init(W.generator_config(7, fmap_base=64, fmap_max=8))   # channels not multiple of 16
 
 
-@pytest.mark.parametrize("gan,batch", [("bedrooms", 1), ("ffhq", 2)])
+@pytest.mark.parametrize("gan,batch", [("bedrooms", 3), ("cars", 1), ("ffhq", 2)])
 def test_full_size_bit_exact(torch_cuda, oracle_lib, gan, batch):
     """BASELINE.json full-size configurations (synthetic weights) against the C oracle."""
     from tests.common import gan_setup
@@ -187,3 +187,36 @@ print("WS_OK")
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSA_WS="1"), capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "WS_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_cli_generate_writes_dataset(torch_cuda, tmp_path):
+    """`main.py generate` (reference main.py:75-104): same config.yml keys, img_%06d.jpg (RGB) and
+    mask_%06d.png (single channel, class index) under BASE_DIR/dataset/train_generated."""
+    import yaml
+    from PIL import Image
+    from gan_segmentation_amd import main as cli
+    from gan_segmentation_amd import params as P
+    from gan_segmentation_amd import weights as W
+    gcfg = W.generator_config(8)                             # bedrooms, 256 px
+    dcfg = W.decoder_config(8)
+    gan_dir, base = tmp_path / "stylegan-models", tmp_path / "exp"
+    gan_dir.mkdir()
+    (base / "checkpoints").mkdir(parents=True)
+    P.save_params(str(gan_dir / "stylegan-bedrooms.params"),
+                  W.generator_names_to_scheme_s(W.synthetic_generator_params(gcfg)))   # structural names
+    P.save_params(str(base / "checkpoints" / "checkpoint_last.params"), W.synthetic_decoder_params(dcfg))
+    cfg = {"BASE_DIR": str(base), "GAN": "bedrooms", "GAN_DIR": str(gan_dir), "GAN_GPU_IDS": [0],
+           "GAN_BATCH_SIZE_PER_GPU": 2, "SOLVER_GPU_IDS": [0], "ANNOTATION": "segmentation", "GENERATE_NUM": 3}
+    (tmp_path / "config.yml").write_text(yaml.safe_dump(cfg))
+    assert cli.main(["generate", "--config", str(tmp_path / "config.yml")]) == 0
+    out = base / "dataset" / "train_generated"
+    names = sorted(p.name for p in out.iterdir())
+    assert names == ["img_000000.jpg", "img_000001.jpg", "img_000002.jpg",
+                     "mask_000000.png", "mask_000001.png", "mask_000002.png"]
+    img = Image.open(out / "img_000001.jpg")
+    mask = np.asarray(Image.open(out / "mask_000001.png"))
+    assert img.size == (256, 256) and img.mode == "RGB"
+    assert mask.shape == (256, 256) and mask.dtype == np.uint8 and set(np.unique(mask)) <= {0, 1}
+    # without a decoder checkpoint the reference prints "train Decoder first!" and exits -1
+    (base / "checkpoints" / "checkpoint_last.params").unlink()
+    assert cli.main(["generate", "--config", str(tmp_path / "config.yml")]) == -1

@@ -25,7 +25,7 @@ def load(name):
 
 
 sq, fe, wr = load("sq1"), load("fetch"), load("write")
-n = len(sq) // 3            # bench ran warm-up 1 + 2 timed steps
+n = len(sq) // 5            # bench ran warm-up 1 + 2 timed steps + 2 roofline-pass steps (all serialized here)
 sq, fe, wr = sq[-n:], fe[-n:], wr[-n:]
 agg = collections.OrderedDict()
 for a, f, w in zip(sq, fe, wr):
