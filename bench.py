@@ -27,7 +27,7 @@ PEAK_HBM_GBS = 8000.0
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_summary.json, produced by tools_pmc.sh + tools_pmc_report.py: separate
+    (profiles/*_pmc_summary.json, produced by tools/pmc.sh + tools/pmc_report.py: separate
     FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if absent."""
     import glob
     best = None
@@ -150,17 +150,16 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # ---- timed region: EXACTLY K steps, every launch bracketed by HIP events on its own stream
-    ctx.profile_enable(1)
-    ctx.profile_reset()
+    # ---- timed region: EXACTLY K steps (no per-launch events here: 2 event packets around each of the
+    # ~130 launches of a step cost ~5 % of the step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    overlapped = {e["name"]: e for e in ctx.profile_entries()}
-    # ---- roofline pass (untimed): the same K steps with the decoder/synthesis stream overlap off, so
-    # that a kernel's duration is its own and not stretched by the kernel running beside it
+    # ---- roofline pass (untimed): the same K steps with every launch bracketed by HIP events on its
+    # stream, and with the decoder/synthesis stream overlap off, so that a kernel's duration is its own
+    # and not stretched by the kernel running beside it
     ctx.set_overlap(0)
     ctx.profile_enable(2 if args.layers else 1)
     ctx.profile_reset()
@@ -187,12 +186,9 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
                     "avg_launch_ms": round(top["ms"] / max(1, top["launches"]), 4),
                     "launches": top["launches"],
-                    "measured": "HIP events around every launch; roofline pass = the same K steps with the "
-                                "decoder-beside-synthesis stream overlap off (durations not stretched by a "
-                                "concurrent kernel); avg_launch_ms_timed_region is the overlapped figure",
-                    "avg_launch_ms_timed_region": round(
-                        overlapped[top["name"].split(" | ")[0]]["ms"] / max(1, overlapped[top["name"].split(" | ")[0]]["launches"]), 4)
-                    if top["name"].split(" | ")[0] in overlapped else None,
+                    "measured": "HIP events around every launch in a second pass of the same K steps, run right "
+                                "after the timed region with the decoder-beside-synthesis stream overlap off "
+                                "(durations not stretched by a concurrent kernel)",
                     "flops_per_launch": round(top["flops"] / max(1, top["launches"])),
                     "algorithmic_bytes_per_launch": round(top["bytes"] / max(1, top["launches"])),
                     "traffic": tr["bytes_per_launch"] if tr else None,

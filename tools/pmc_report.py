@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarises the PMC passes of tools_pmc.sh (gpurun_out/pmc/*_counter_collection.csv) per kernel
+"""Summarises the PMC passes of tools/pmc.sh (gpurun_out/pmc/*_counter_collection.csv) per kernel
 symbol over the LAST timed bench step and writes profiles/<tag>_pmc_summary.json.
 
 FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads -- MI355X_MICROARCH.md
@@ -54,7 +54,7 @@ for name, e in agg.items():
         "lds_conflict_per_active_inst": e["lds_conflict"] / e["active_inst"] if e["active_inst"] else 0.0,
     })
 rows.sort(key=lambda r: -r["avg_us_in_pmc_pass"] * r["launches_per_step"])
-json.dump({"source": "rocprofv3 --pmc passes (tools_pmc.sh), last timed step of bench.py --steps 2", "kernels": rows},
+json.dump({"source": "rocprofv3 --pmc passes (tools/pmc.sh), last timed step of bench.py --steps 2", "kernels": rows},
           open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1)
 print("%-62s %5s %9s %8s %8s %6s" % ("kernel", "n", "us/launch", "fetchMB", "writeMB", "mfma%"))
 for r in rows[:16]:

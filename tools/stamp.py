@@ -2,7 +2,7 @@
 """Diagnostic: run one FFHQ batch through the stamp build (csrc/libgsa_hip_stamp.so, `make stamp`)
 and print the per-phase wave-cycle averages of every conv launch (stderr lines `STAMP ...`)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gan_segmentation_amd import _lib
 _lib.HIP_LIBRARY = os.path.join(os.path.dirname(_lib.HIP_LIBRARY), "libgsa_hip_stamp.so")
