@@ -32,6 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Diagnostic build only (make stamp): s_memtime stamps at the phase boundaries of the conv
 // kernel, summed per phase into ConvParams::stamps.  No stamp executes in the product build.
 #ifdef GSA_STAMP
+#define GSA_DBG_HOOKS 1
+#endif
+#ifdef GSA_STAMP
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define STAMP_DECL unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP_FLUSH(nph) do { if (p.stamps && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < (nph); ++i_) atomicAdd(&p.stamps[i_], stamp_t[i_ + 1] - stamp_t[i_]); atomicAdd(&p.stamps[15], 1ull); } } while (0)
@@ -147,10 +150,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
     constexpr int BIT = (NB4 + NTHR - 1) / NTHR;
     constexpr int SIT = (Q * 64 + NTHR - 1) / NTHR;   // shortcut weights: Q*256 floats
     constexpr int FIT = (512 + NTHR - 1) / NTHR;      // AdaIN table: up to 512 input channels
+    // DB: double-buffered LDS images for the narrow channel tiles (<= 32 output channels): the LDS
+    // write of item i+1 no longer has to wait for the readers of item i, so it sits in front of
+    // the MFMAs of item i in the same wave (one barrier per item instead of two) and its VALU/LDS
+    // instructions issue in the gaps of the MFMA stream
+    constexpr bool DB = Q <= 2 && !SC && TH == 16;
+    constexpr int NBUF = DB ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;
-    float* sB = sA + LH * RS;                    // [q][tap][ci][16][cg]
-    float* sS = sB + Q * SEG;                    // SC: [q][ci][16][cg]
+    float* sA = smem;                            // [NBUF][LH*RS]
+    float* sB = sA + NBUF * LH * RS;             // [NBUF][q][tap][ci][16][cg]
+    float* sS = sB + NBUF * Q * SEG;             // SC: [q][ci][16][cg]
     f32x4* sAff = reinterpret_cast<f32x4*>(sS + (SC ? Q * 256 : 0));   // [C0] (mean, A, B, -)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -185,6 +194,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
             const bool inside = stage && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             tp[it].lds = stage ? ly * RS + lx * 16 : -1;
             tp[it].pix = inside ? (t.n * p.Hs + (gy >> p.up)) * p.Ws + (gx >> p.up) : -1;
+#ifdef GSA_DBG_HOOKS
+            if ((p.dbg & 1) && inside) tp[it].pix = lx & 1;      // timing-only: cache-resident input
+#endif
         }
     };
 
@@ -245,89 +257,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < FIT; ++j) sAff[min(tid + j * NTHR, p.C0 - 1)] = rf[j];
     };
-    auto write_item = [&](int cb, const TilePixel (&tp)[AIT]) {
+    auto write_item = [&](int cb, const TilePixel (&tp)[AIT], int buf = 0) {
+        float* a_img = sA + buf * (LH * RS);
         if (cb < nblk0 && has_aff) {      // wave-uniform
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<true>(sA, ra[it], reinterpret_cast<const float4*>(sAff) + cb * 16, tp[it]);
+            for (int it = 0; it < AIT; ++it) store_pixel<true>(a_img, ra[it], reinterpret_cast<const float4*>(sAff) + cb * 16, tp[it]);
         } else {
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<false>(sA, ra[it], reinterpret_cast<const float4*>(sAff), tp[it]);
+            for (int it = 0; it < AIT; ++it) store_pixel<false>(a_img, ra[it], reinterpret_cast<const float4*>(sAff), tp[it]);
         }
 #pragma unroll
-        for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB)[min(tid + j * NTHR, NB4 - 1)] = rb[j];
+        for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * (Q * SEG))[min(tid + j * NTHR, NB4 - 1)] = rb[j];
         if (SC) {
 #pragma unroll
             for (int j = 0; j < SIT; ++j) reinterpret_cast<f32x4*>(sS)[min(tid + j * NTHR, Q * 64 - 1)] = rs[j];
         }
     };
 
-    WorkTile tc = decode(w_begin);
-    TilePixel tp[AIT], tpn[AIT];
-    tile_pixels(tc, tp);
-    load_item(tc, 0, tp);
-    int n_aff = tc.n;
-    if (has_aff) {
-        write_aff();
-        __syncthreads();
-    }
-#ifdef GSA_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    STAMP(1);                                      // [0,1): prologue + first global loads landed
-    write_item(0, tp);
-    STAMP(2);                                      // [1,2): first LDS write
-    __syncthreads();
-    STAMP(3);                                      // [2,3): barrier
-
-    int w = w_begin, cb = 0;
-    while (true) {
-        // ---- the next item (or a harmless reload of this one when it is the last)
-        int w2 = w, cb2 = cb + 1;
-        if (cb2 == nblk) { cb2 = 0; w2 = w + 1; }
-        const bool has_next = w2 < w_end;
-        if (!has_next) { w2 = w; cb2 = cb; }
-        WorkTile tn = tc;
-        if (w2 != w) {
-            tn = decode(w2);
-            tile_pixels(tn, tpn);
-        } else {
-#pragma unroll
-            for (int it = 0; it < AIT; ++it) tpn[it] = tp[it];
-        }
-        load_item(tn, cb2, tpn);                   // in flight during the MFMAs and the epilogue below
-        __builtin_amdgcn_sched_barrier(0);         // keep the consumers of those loads below the MFMAs
-        // ---- MFMA: K order (tap, cg, ci) inside the block
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = (tap / 3) * RS + (tap % 3) * 16;
-            f32x4 a[MT], b[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(sA + abase[mt] + toff);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(sB + bbase + nt * SEG + tap * 256);
-#pragma unroll
-            for (int cg = 0; cg < 4; ++cg)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
-            if (SC && tap == 4) {  // 1x1 shortcut on the centre tap, natural channel order
-                f32x4 bs[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bs[nt] = *reinterpret_cast<const f32x4*>(sS + sbase + nt * 256);
-#pragma unroll
-                for (int cg = 0; cg < 4; ++cg)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            accs[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], bs[nt][cg], accs[mt][nt], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        if (cb == nblk - 1) {
+    auto epilogue = [&](const WorkTile& tc) {
             // ---- epilogue of tile tc.  C layout: lane -> (channel = lane&15, patch row = lane>>4),
             // reg -> patch column.  Every global load (noise, residual, per-channel constants) is
             // issued before the first store: a load cannot move above a store that might alias it.
@@ -398,6 +345,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
                             if (has_resid) v[r] = rr[mt][nt][r] + v[r];
                         }
                     }
+#ifdef GSA_DBG_HOOKS
+                    if (!(p.dbg & 4))      // timing-only: no epilogue stores
+#endif
 #pragma unroll
                     for (int r = 0; r < 4; ++r) p.out[(pix + r) * p.Cout + co] = v[r];
                     if (SC) {
@@ -416,7 +366,131 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
                     }
                 }
             }
+            };
+
+    auto mfma_item = [&](int buf) {
+        const float* a_img = sA + buf * (LH * RS);
+        const float* b_img = sB + buf * (Q * SEG);
+        // ---- MFMA: K order (tap, cg, ci) inside the block
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * RS + (tap % 3) * 16;
+            f32x4 a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_img + abase[mt] + toff);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(b_img + bbase + nt * SEG + tap * 256);
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
+            if (SC && tap == 4) {  // 1x1 shortcut on the centre tap, natural channel order
+                f32x4 bs[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bs[nt] = *reinterpret_cast<const f32x4*>(sS + sbase + nt * 256);
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            accs[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], bs[nt][cg], accs[mt][nt], 0, 0, 0);
+            }
         }
+    };
+
+    if constexpr (DB) {
+        // items in flight: `tc/cb` is being multiplied out of LDS buffer it&1, `tr/cbr` sits in the
+        // prefetch registers (written to buffer (it+1)&1 at the top of the next iteration)
+        const int total_items = (w_end - w_begin) * nblk;
+        auto item_at = [&](int i, WorkTile& t, int& cbi) {
+            const int ic = min(i, total_items - 1);
+            t = decode(w_begin + ic / nblk);
+            cbi = ic % nblk;
+        };
+        WorkTile tc, tr;
+        int cb = 0, cbr = 0;
+        TilePixel tpr[AIT];
+        item_at(0, tc, cb);
+        tile_pixels(tc, tpr);
+        load_item(tc, cb, tpr);
+        int n_aff = tc.n;
+        if (has_aff) {
+            write_aff();
+            __syncthreads();
+        }
+        write_item(cb, tpr, 0);
+        item_at(1, tr, cbr);
+        tile_pixels(tr, tpr);
+        load_item(tr, cbr, tpr);
+        if (has_aff && total_items > 1 && tr.n != n_aff) {     // table of item 1's sample (buffer reuse is safe: item 0 is staged)
+            __syncthreads();
+            write_aff();
+            n_aff = tr.n;
+        }
+        __syncthreads();
+        for (int it = 0; it < total_items; ++it) {
+            const bool has_next = it + 1 < total_items;
+            if (has_next) write_item(cbr, tpr, (it + 1) & 1);  // item it+1: registers -> the other LDS buffer
+            WorkTile t2; int cb2;
+            item_at(it + 2, t2, cb2);
+            tile_pixels(t2, tpr);
+            load_item(t2, cb2, tpr);                           // item it+2 -> registers, lands during the MFMAs
+            mfma_item(it & 1);
+            if (cb == nblk - 1) epilogue(tc);
+            if (has_aff && it + 2 < total_items && t2.n != n_aff) {   // wave-uniform, rare: next sample's AdaIN table
+                __syncthreads();                                      // item it+1 (old table) is staged by every wave
+                write_aff();
+                n_aff = t2.n;
+            }
+            __syncthreads();
+            tc = tr; cb = cbr; tr = t2; cbr = cb2;
+        }
+        return;
+    }
+
+    WorkTile tc = decode(w_begin);
+    TilePixel tp[AIT], tpn[AIT];
+    tile_pixels(tc, tp);
+    load_item(tc, 0, tp);
+    int n_aff = tc.n;
+    if (has_aff) {
+        write_aff();
+        __syncthreads();
+    }
+#ifdef GSA_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(1);                                      // [0,1): prologue + first global loads landed
+    write_item(0, tp);
+    STAMP(2);                                      // [1,2): first LDS write
+    __syncthreads();
+    STAMP(3);                                      // [2,3): barrier
+
+    int w = w_begin, cb = 0;
+    while (true) {
+        // ---- the next item (or a harmless reload of this one when it is the last)
+        int w2 = w, cb2 = cb + 1;
+        if (cb2 == nblk) { cb2 = 0; w2 = w + 1; }
+        const bool has_next = w2 < w_end;
+        if (!has_next) { w2 = w; cb2 = cb; }
+        WorkTile tn = tc;
+        if (w2 != w) {
+            tn = decode(w2);
+            tile_pixels(tn, tpn);
+        } else {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) tpn[it] = tp[it];
+        }
+        load_item(tn, cb2, tpn);                   // in flight during the MFMAs and the epilogue below
+        __builtin_amdgcn_sched_barrier(0);         // keep the consumers of those loads below the MFMAs
+        mfma_item(0);
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (cb == nblk - 1) epilogue(tc);
         if (!has_next) break;
         __syncthreads();              // every wave has finished reading this item's LDS image
         if (has_aff && tn.n != n_aff) {   // wave-uniform: the next item belongs to another sample
@@ -809,6 +883,9 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
         const bool inside = stage && gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws;
         tp.lds = stage ? ly * RS + lx * 16 : -1;
         tp.pix = inside ? (n * p.Hs + gy) * p.Ws + gx : -1;
+#ifdef GSA_DBG_HOOKS
+        if ((p.dbg & 1) && inside) tp.pix = lx & 1;              // timing-only: cache-resident input
+#endif
     }
     int abase[4];
 #pragma unroll
@@ -942,6 +1019,9 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
                     const float yv = v + e0[nt];
                     v = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
                 }
+#ifdef GSA_DBG_HOOKS
+                if (!(p.dbg & 4))
+#endif
                 p.out[o] = v;
             }
         }
@@ -1398,7 +1478,8 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int Q = NT * WN, COUT_T = 16 * Q;
     constexpr int RS = (TW + 2) * 16 + 8;
     if (p.C0 > 512 && p.aff0) return hipErrorInvalidValue;   // AdaIN table registers sized for <= 512 channels
-    const size_t lds = sizeof(float) * ((TH + 2) * RS + Q * 9 * 256 + (SC ? Q * 256 : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
+    constexpr int NBUF = (Q <= 2 && !SC && TH == 16) ? 2 : 1;   // must match the kernel's DB
+    const size_t lds = sizeof(float) * (NBUF * ((TH + 2) * RS + Q * 9 * 256) + (SC ? Q * 256 : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
     auto kern = conv3x3_mfma<TH, TW, WM, WN, NT, EPI, SC>;
     static bool attr_done = false;
     if (!attr_done) {
