@@ -782,8 +782,8 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
             if (!d.is_last) {
                 if (int rc = dev_alloc(c, N * 4 * R * R * d.cs, &c->ya[i], T)) return rc;
                 if (int rc = dev_alloc(c, N * 4 * R * R * d.cs, &c->prev[i], T)) return rc;
-                if (d.has_sc)   // shortcut at the INPUT resolution when the sub-pixel kernel produces it
-                    if (int rc = dev_alloc(c, N * 4 * R * R * d.cs, &c->scb[i], T)) return rc;
+                if (d.has_sc)   // shortcut at the INPUT resolution when the sub-pixel kernel produces it (outputs >= 16 px)
+                    if (int rc = dev_alloc(c, N * (2 * R >= 16 ? 1 : 4) * R * R * d.cs, &c->scb[i], T)) return rc;
             }
         }
     }
