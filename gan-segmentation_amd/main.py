@@ -19,10 +19,10 @@ def load_config_file(path):
         return yaml.safe_load(f)   # reference utils.py:112-115
 
 
-def generate(cfg, limit=None):
+def generate(cfg, limit=None, workers=None):
     import torch
-    from PIL import Image
     from . import dist as gdist
+    from .dataset_writer import DatasetWriter
     from .image_generator import ImageGenerator
     from .seg_solver import SegSolver
     from .weights import GAN_MAX_RES_LOG2
@@ -46,15 +46,15 @@ def generate(cfg, limit=None):
 
     lo, hi = gdist.shard_bounds(n_generate, world, rank)
     index = lo
-    while index < hi:
-        bs = min(batch, hi - index)
-        img, mask = netG.generate_batch(netG.draw_latents(bs))
-        torch.cuda.synchronize()
-        img, mask = img.cpu().numpy(), mask.cpu().numpy()
-        for i in range(bs):
-            Image.fromarray(img[i], "RGB").save(os.path.join(dst_dir, "img_%06d.jpg" % (index + i)), quality=95)
-            Image.fromarray(mask[i], "L").save(os.path.join(dst_dir, "mask_%06d.png" % (index + i)))
-        index += bs
+    # the writer copies each batch out through pinned buffers and encodes it on a thread pool while the
+    # GPU already computes the next one
+    with DatasetWriter(dst_dir, workers=workers) as writer:
+        while index < hi:
+            bs = min(batch, hi - index)
+            img, mask = netG.generate_batch(netG.draw_latents(bs))
+            writer.submit(img, mask, index)
+            index += bs
+    torch.cuda.synchronize()
     return 0
 
 
@@ -63,12 +63,13 @@ def main(argv=None):
     ap.add_argument("action", nargs="?", choices=("annotation", "train", "evaluate", "generate"), default="generate")
     ap.add_argument("--config", default="config.yml")
     ap.add_argument("--limit", type=int, default=None, help="override GENERATE_NUM")
+    ap.add_argument("--workers", type=int, default=None, help="encoder threads (default: the CPU share of the process)")
     args = ap.parse_args(argv)
     if args.action != "generate":
         print("only the `generate` action is implemented by the MI355X path (SURVEY.md section 8)")
         return 2
     np.random.seed(0)
-    return generate(load_config_file(args.config), args.limit)
+    return generate(load_config_file(args.config), args.limit, args.workers)
 
 
 if __name__ == "__main__":

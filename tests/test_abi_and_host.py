@@ -126,3 +126,27 @@ def test_world_size_2_gather_on_gloo(tmp_path, oracle_lib):
         capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "GATHER_OK" in out.stdout
+
+
+def test_dataset_writer_files_and_throughput(tmp_path):
+    """The asynchronous writer: names, formats and contents of reference main.py:100-103."""
+    import time
+    from PIL import Image
+    from gan_segmentation_amd.dataset_writer import DatasetWriter
+    rng = np.random.default_rng(0)
+    n, R = 12, 256
+    ramp = np.arange(R, dtype=np.uint8)
+    img = np.stack([np.broadcast_to(ramp[None, None, :], (n, R, R)), np.broadcast_to(ramp[None, :, None], (n, R, R)),
+                    np.full((n, R, R), 90, np.uint8)], axis=-1).copy()    # smooth ramps survive JPEG
+    mask = (rng.random((n, R, R)) > 0.5).astype(np.uint8)
+    t0 = time.perf_counter()
+    with DatasetWriter(str(tmp_path), workers=4) as w:
+        w.submit(img[:8], mask[:8], 0)
+        w.submit(img[8:], mask[8:], 8)
+    assert w.written == n and time.perf_counter() - t0 < 60
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted(["img_%06d.jpg" % i for i in range(n)] + ["mask_%06d.png" % i for i in range(n)])
+    m = np.asarray(Image.open(tmp_path / "mask_000009.png"))
+    assert m.dtype == np.uint8 and np.array_equal(m, mask[9])             # PNG is lossless: class indices intact
+    j = np.asarray(Image.open(tmp_path / "img_000003.jpg"))
+    assert j.shape == (R, R, 3) and np.abs(j.astype(int) - img[3].astype(int)).mean() < 3
