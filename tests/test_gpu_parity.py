@@ -220,3 +220,20 @@ def test_cli_generate_writes_dataset(torch_cuda, tmp_path):
     # without a decoder checkpoint the reference prints "train Decoder first!" and exits -1
     (base / "checkpoints" / "checkpoint_last.params").unlink()
     assert cli.main(["generate", "--config", str(tmp_path / "config.yml")]) == -1
+
+
+def test_config4_bedrooms_batch64_and_workspace_growth(torch_cuda):
+    """BASELINE config 4 (bedrooms 256 px, batch 64) runs, and a sample's bytes do not depend on the
+    batch it rides in (the batch-3 result is the one checked bit-exact against the oracle above);
+    the workspace grows when a larger batch follows a smaller one."""
+    from tests.common import gan_setup
+    gcfg, gp, dcfg, dp, z, noise = gan_setup("bedrooms", 64)
+    gen = _build(gcfg, gp, dcfg, dp, 64)
+    i3, m3 = gen.generate_batch(z[:3], [a[:3] for a in noise])          # reserves 3
+    i64, m64 = gen.generate_batch(z, noise)                              # grows to 64
+    i1, m1 = gen.generate_batch(z[63:], [a[63:] for a in noise])
+    assert_same(i64[:3].cpu().numpy(), i3.cpu().numpy(), "batch-64 vs batch-3 image")
+    assert_same(m64[:3].cpu().numpy(), m3.cpu().numpy(), "batch-64 vs batch-3 mask")
+    assert_same(i64[63:].cpu().numpy(), i1.cpu().numpy(), "last sample image")
+    assert_same(m64[63:].cpu().numpy(), m1.cpu().numpy(), "last sample mask")
+    assert 0.001 < m64.float().mean().item() < 0.999
