@@ -150,3 +150,23 @@ def test_dataset_writer_files_and_throughput(tmp_path):
     assert m.dtype == np.uint8 and np.array_equal(m, mask[9])             # PNG is lossless: class indices intact
     j = np.asarray(Image.open(tmp_path / "img_000003.jpg"))
     assert j.shape == (R, R, 3) and np.abs(j.astype(int) - img[3].astype(int)).mean() < 3
+
+
+def test_annotation_sample_files(tmp_path):
+    """img_%06d.jpg + feat_%06d.pickle as the annotator saves them, mask thresholds as the
+    few-shot dataset applies them (reference seg_annotator.py:322-337, seg_datasets.py:60-106)."""
+    import pickle
+    from PIL import Image
+    from gan_segmentation_amd import annotation_io as A
+    rng = np.random.default_rng(1)
+    feats = [rng.normal(size=(c, r, r)).astype(np.float32) for c, r in ((32, 4), (32, 8), (16, 16))]
+    img = np.full((16, 16, 3), 120, np.uint8)
+    A.export_sample(str(tmp_path), 7, img, feats)
+    assert sorted(os.listdir(tmp_path)) == ["feat_000007.pickle", "img_000007.jpg"]
+    with open(tmp_path / "feat_000007.pickle", "rb") as fp:
+        back = pickle.load(fp)                                   # a plain list of CHW fp32 arrays
+    assert isinstance(back, list) and all(np.array_equal(a, b) and a.dtype == np.float32 for a, b in zip(back, feats))
+    Image.fromarray(np.array([[0, 63, 64], [192, 193, 255]], np.uint8), "L").save(tmp_path / "mask_000007.png")
+    Image.fromarray(np.full((2, 3, 3), 10, np.uint8), "RGB").save(tmp_path / "img_000007.jpg")
+    mask, img2, f2 = A.load_sample(str(tmp_path), 7)
+    assert mask.tolist() == [[-1, -1, 0], [0, 1, 1]] and img2.shape == (2, 3, 3) and len(f2) == 3
