@@ -65,6 +65,23 @@ __device__ __forceinline__ float dpp_quad(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 
+// 4x4 transpose across the four lanes of an aligned quad (two DPP butterfly steps, no LDS): lane j
+// enters with M[r][j] in register r and leaves with M[j][r].  The MFMA C layout (lane = channel,
+// register = x) becomes (lane = x, registers = 4 consecutive channels): one 16-byte access per lane
+// instead of four dword accesses, and the 16 lanes of a patch row cover 4 whole pixels.
+__device__ __forceinline__ f32x4 quad_transpose(float v0, float v1, float v2, float v3, int j) {
+    const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0;
+    float pa = dpp_quad<0xB1>(v0), pb = dpp_quad<0xB1>(v1);
+    const float a0 = b0 ? pb : v0, a1 = b0 ? v1 : pa;
+    pa = dpp_quad<0xB1>(v2); pb = dpp_quad<0xB1>(v3);
+    const float a2 = b0 ? pb : v2, a3 = b0 ? v3 : pa;
+    pa = dpp_quad<0x4E>(a0); pb = dpp_quad<0x4E>(a2);
+    const float c0 = b1 ? pb : a0, c2 = b1 ? a2 : pa;
+    pa = dpp_quad<0x4E>(a1); pb = dpp_quad<0x4E>(a3);
+    const float c1 = b1 ? pb : a1, c3 = b1 ? a3 : pa;
+    return f32x4{c0, c1, c2, c3};
+}
+
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
     unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
     lo = __shfl_xor(lo, m);
@@ -297,24 +314,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
                 if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
                 if (SC) scb[nt] = p.sc_bias[co];
             }
-            float rr[EPI == EPI_DEC ? MT : 1][EPI == EPI_DEC ? NT : 1][4];
+            // residual and stores use the quad-transposed layout: lane -> (x = lane&3, channels 4*((lane>>2)&3)..+3)
+            const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;
+            f32x4 rr[EPI == EPI_DEC ? MT : 1][EPI == EPI_DEC ? NT : 1];
             const bool has_resid = EPI == EPI_DEC && p.resid != nullptr;
             if (EPI == EPI_DEC && has_resid) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
-                    const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4;
+                    const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4 + xj;
+                    const size_t rp = p.resid_up ? (size_t)(tc.n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1)
+                                                 : pixs[mt] + xj;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int co = tc.g * COUT_T + (wn * NT + nt) * 16 + i16;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const size_t rp = p.resid_up
-                                                  ? (size_t)(tc.n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + ((x + r) >> 1)
-                                                  : pixs[mt] + r;
-                            rr[mt][nt][r] = p.resid[rp * p.Cout + co];
-                        }
-                    }
+                    for (int nt = 0; nt < NT; ++nt)
+                        rr[mt][nt] = *reinterpret_cast<const f32x4*>(p.resid + rp * p.Cout + tc.g * COUT_T + (wn * NT + nt) * 16 + cq4);
                 }
             }
 #pragma unroll
@@ -342,17 +355,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
                         for (int r = 0; r < 4; ++r) {
                             const float yv = v[r] + e0[nt];
                             v[r] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
-                            if (has_resid) v[r] = rr[mt][nt][r] + v[r];
                         }
+                    }
+                    const size_t ot = (pix + xj) * p.Cout + tc.g * COUT_T + (wn * NT + nt) * 16 + cq4;
+                    f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
+                    if (EPI == EPI_DEC && has_resid) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vt[r] = rr[mt][nt][r] + vt[r];
                     }
 #ifdef GSA_DBG_HOOKS
                     if (!(p.dbg & 4))      // timing-only: no epilogue stores
 #endif
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p.out[(pix + r) * p.Cout + co] = v[r];
+                    *reinterpret_cast<f32x4*>(p.out + ot) = vt;
                     if (SC) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) p.out_sc[(pix + r) * p.Cout + co] = accs[mt][nt][r] + scb[nt];
+                        *reinterpret_cast<f32x4*>(p.out_sc + ot) =
+                            quad_transpose(accs[mt][nt][0] + scb[nt], accs[mt][nt][1] + scb[nt], accs[mt][nt][2] + scb[nt],
+                                           accs[mt][nt][3] + scb[nt], xj);
                     }
                     acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (SC) accs[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1004,34 +1022,35 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
         if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
         if (SC) scb[nt] = p.sc_bias[co];
     }
+    // stores in the quad-transposed layout: lane -> (x = lane&3, channels 4*((lane>>2)&3)..+3), 16 bytes each
+    const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = g * COUT_T + nt * 16 + i16;
+        const int cot = g * COUT_T + nt * 16 + cq4;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int oy = y0 + 2 * ((mt >> 1) * 4 + (lane >> 4)) + py;
+            const int ox = x0 + 2 * ((mt & 1) * 4 + xj) + px;
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ox = x0 + 2 * ((mt & 1) * 4 + r) + px;
-                const size_t o = ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + co;
-                float v = acc[mt][nt][r];
+                v[r] = acc[mt][nt][r];
                 if (EPI == EPI_DEC) {
-                    const float yv = v + e0[nt];
-                    v = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
+                    const float yv = v[r] + e0[nt];
+                    v[r] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
                 }
-#ifdef GSA_DBG_HOOKS
-                if (!(p.dbg & 4))
-#endif
-                p.out[o] = v;
             }
+            const f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
+#ifdef GSA_DBG_HOOKS
+            if (!(p.dbg & 4))
+#endif
+            *reinterpret_cast<f32x4*>(p.out + ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + cot) = vt;
         }
         if (SC) {
             const int iy = y0 / 2 + (wave >> 1) * 4 + (lane >> 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ix = x0 / 2 + (wave & 1) * 4 + r;
-                p.out_sc[((size_t)(n * p.Hs + iy) * p.Ws + ix) * p.Cout + co] = accs[nt][r] + scb[nt];
-            }
+            const int ix = x0 / 2 + (wave & 1) * 4 + xj;
+            *reinterpret_cast<f32x4*>(p.out_sc + ((size_t)(n * p.Hs + iy) * p.Ws + ix) * p.Cout + cot) =
+                quad_transpose(accs[nt][0] + scb[nt], accs[nt][1] + scb[nt], accs[nt][2] + scb[nt], accs[nt][3] + scb[nt], xj);
         }
     }
 }
