@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gan", default="ffhq", choices=("ffhq", "cars", "bedrooms"))
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU per step")
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"),
+                    help="bf16 = bf16 MFMA operands, fp32 accumulate/statistics (BASELINE.json configs[4]); "
+                         "the headline metric is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="per-layer kernel breakdown on stderr")
     args = ap.parse_args()
@@ -128,7 +131,8 @@ def main():
     mr = W.GAN_MAX_RES_LOG2[args.gan]
     gcfg, dcfg = W.generator_config(mr), W.decoder_config(mr)
     gp, dp = W.synthetic_generator_params(gcfg, seed=2), W.synthetic_decoder_params(dcfg, seed=3)
-    gen = ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[local_rank], batch_size=args.batch)
+    gen = ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[local_rank], batch_size=args.batch,
+                                     precision=args.precision)
     B = args.batch
     # per-rank inputs keyed by global sample index, resident in HBM before the timed region
     z, noise = W.synthetic_inputs(gcfg, B, seed_z=1000 + rank, seed_noise=2000 + rank)
@@ -182,8 +186,12 @@ def main():
         kms = sum(e["ms"] for e in entries)
         ach = top["flops"] / (top["ms"] * 1e-3) / 1e12 if top["ms"] > 0 else 0.0
         tr = pmc_traffic(top["name"])
-        roofline = {"bound": "mfma", "kernel": top["name"], "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
+        bound, peak, unit = "mfma", PEAK_FP32_TFLOPS, "TFLOP/s"
+        if args.precision == "bf16":     # 16x the MFMA rate: the same kernels sit under the HBM roof
+            bound, peak, unit = "hbm", PEAK_HBM_GBS, "GB/s"
+            ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9 if top["ms"] > 0 else 0.0
+        roofline = {"bound": bound, "kernel": top["name"], "achieved": round(ach, 3), "peak": peak,
+                    "unit": unit, "frac": round(ach / peak, 4),
                     "avg_launch_ms": round(top["ms"] / max(1, top["launches"]), 4),
                     "launches": top["launches"],
                     "measured": "HIP events around every launch in a second pass of the same K steps, run right "
@@ -197,10 +205,12 @@ def main():
             "metric": "synthetic (image,mask) pairs/sec, %s-%d StyleGAN+decoder" % (args.gan.upper(), 2 ** mr),
             "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "stylegan-%s %d^2 synthesis + %d-class decoder, batch=%d per GPU, fp32 "
-                                   "(BASELINE.json configs[1]); synthetic weights/latents/noise; (img u8, mask u8) "
-                                   "resident on rank 0" % (args.gan, 2 ** mr, dcfg["num_classes"], B),
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": "stylegan-%s %d^2 synthesis + %d-class decoder, batch=%d per GPU, %s; "
+                                   "synthetic weights/latents/noise; (img u8, mask u8) resident on rank 0"
+                                   % (args.gan, 2 ** mr, dcfg["num_classes"], B,
+                                      "fp32 (BASELINE.json configs[1])" if args.precision == "fp32" else
+                                      "bf16 MFMA operands, fp32 accumulate and statistics (BASELINE.json configs[4])"),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "roofline": roofline,
             "whole_path": {

@@ -18,13 +18,16 @@ HIP_LIBRARY = os.path.join(_HERE, "csrc", "libgsa_hip.so")
 API_SYMBOLS = (
     "create", "destroy", "last_error", "generator_init", "generator_set_param",
     "generator_commit", "decoder_init", "decoder_set_param", "decoder_commit", "reserve",
-    "generator_forward", "decoder_forward", "generate", "set_overlap", "profile_enable", "profile_collect",
+    "generator_forward", "decoder_forward", "generate", "set_overlap", "set_precision", "profile_enable", "profile_collect",
     "profile_entry", "profile_reset", "version",
 )
 
 
 class GsaError(RuntimeError):
     pass
+
+
+PRECISIONS = {"fp32": 0, "bf16": 1}     # gsa_precision
 
 
 class GeneratorConfig(ctypes.Structure):
@@ -67,6 +70,7 @@ class Api:
             "decoder_forward": (c.c_int, [vp, vp, i32, c.POINTER(vp), vp, vp]),
             "generate": (c.c_int, [vp, vp, i32, vp, c.POINTER(vp), vp, vp]),
             "set_overlap": (c.c_int, [vp, i32]),
+            "set_precision": (c.c_int, [vp, i32]),
             "profile_enable": (c.c_int, [vp, i32]),
             "profile_collect": (c.c_int, [vp]),
             "profile_entry": (c.c_int, [vp, i32, c.POINTER(c.c_char_p), c.POINTER(c.c_double),
@@ -117,6 +121,7 @@ class Context:
         self.device = device
         self.generator_cfg = None
         self.decoder_cfg = None
+        self.precision = "fp32"
 
     def _msg(self, h):
         m = self.api.last_error(h)
@@ -193,6 +198,11 @@ class Context:
 
     def generate(self, stream, n, z, noise, img, mask):
         self._check(self.api.generate(self._h, stream, n, z, _ptr_array(noise), img, mask), "generate")
+
+    def set_precision(self, precision):
+        """"fp32" (default, bit-exact canonical path) or "bf16" (bf16 MFMA operands); before the weights are loaded."""
+        self._check(self.api.set_precision(self._h, PRECISIONS[precision]), "set_precision")
+        self.precision = precision
 
     def set_overlap(self, levels):
         self._check(self.api.set_overlap(self._h, int(levels)), "set_overlap")

@@ -25,25 +25,30 @@ def to_device_f32(x, device):
 
 
 class DeviceModel:
-    """A ``gsa_ctx`` bound to one torch device, shared by Generator and Decoder objects that
-    live on the same GPU (so the fused ``generate`` call sees both networks)."""
+    """A ``gsa_ctx`` bound to one torch device and one arithmetic ("fp32" / "bf16" MFMA operands), shared by
+    Generator and Decoder objects that live on the same GPU (so the fused ``generate`` call sees both)."""
 
     _by_device = {}
 
-    def __init__(self, device_index):
+    def __init__(self, device_index, precision="fp32"):
         require_gpu()
+        if precision not in _lib.PRECISIONS:
+            raise _lib.GsaError("precision must be one of %s" % sorted(_lib.PRECISIONS))
         self.device = torch.device("cuda", device_index)
+        self.precision = precision
         self.ctx = _lib.Context(_lib.load_library(), device_index)
+        if precision != "fp32":
+            self.ctx.set_precision(precision)
         self.reserved = 0
         self.generator_cfg = None
         self.decoder_cfg = None
 
     @classmethod
-    def get(cls, device_index=0):
-        m = cls._by_device.get(device_index)
+    def get(cls, device_index=0, precision="fp32"):
+        m = cls._by_device.get((device_index, precision))
         if m is None:
-            m = cls(device_index)
-            cls._by_device[device_index] = m
+            m = cls(device_index, precision)
+            cls._by_device[(device_index, precision)] = m
         return m
 
     def ensure_batch(self, n):

@@ -116,6 +116,7 @@ struct gsa_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_level[kMaxLevels] = {nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int bf16 = 0;                 // gsa_set_precision: 1 = bf16 MFMA operands (fixed once weights are committed)
     int side_levels = kMaxLevels; // decoder levels 0..side_levels-1 (all but the last) go to the side stream (GSA_SIDE_LEVELS)
 
     // profiling
@@ -162,6 +163,30 @@ int upload(gsa_ctx* c, const std::vector<float>& h, float** out, std::vector<voi
     HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     *out = (float*)d;
     return GSA_OK;
+}
+
+// round-to-nearest-even fp32 -> bf16 (what v_cvt_pk_bf16_f32 does to the activations)
+inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// Upload of an MFMA weight pack (a sequence of 256-float [ci][16][cg] chunks, one per tap and
+// (16 couts, 16 channels) pair).  bf16 mode: each chunk becomes [kq][16][4] bf16 with channel = 4*kq+j,
+// the k order of v_mfma_f32_16x16x16_bf16 -- half the bytes, addressed in the same 4-byte slots.
+int upload_mfma(gsa_ctx* c, const std::vector<float>& h, float** out, std::vector<void*>& track) {
+    if (!c->bf16) return upload(c, h, out, track);
+    std::vector<float> packed(h.size() / 2);
+    uint16_t* o = reinterpret_cast<uint16_t*>(packed.data());
+    for (size_t chunk = 0; chunk < h.size() / 256; ++chunk)
+        for (int ci = 0; ci < 4; ++ci)
+            for (int n = 0; n < 16; ++n)
+                for (int cg = 0; cg < 4; ++cg)
+                    o[chunk * 256 + (cg * 16 + n) * 4 + ci] = bf16_rne(h[chunk * 256 + (ci * 16 + n) * 4 + cg]);
+    return upload(c, packed, out, track);
 }
 
 template <typename T>
@@ -400,10 +425,10 @@ struct Launch {
     }
 };
 
-const char* conv_kernel_name(int H, int Cout, int n, int epi, bool sc) {
-    static thread_local char buf[96];
-    snprintf(buf, sizeof buf, "void gsa::conv3x3_mfma<%s, %d, %s>(gsa::ConvParams)", conv_geom_name(H, H, Cout, n), epi,
-             sc ? "true" : "false");
+const char* conv_kernel_name(const gsa_ctx* c, int H, int Cout, int n, int epi, bool sc) {
+    static thread_local char buf[112];
+    snprintf(buf, sizeof buf, "void gsa::conv3x3_mfma<%s, %d, %s, %s>(gsa::ConvParams)", conv_geom_name(H, H, Cout, n), epi,
+             sc ? "true" : "false", c->bf16 ? "true" : "false");
     return buf;
 }
 
@@ -550,7 +575,7 @@ int gsa_generator_commit(gsa_ctx* c) {
                 NEED(P, std::string(nm) + "_weight", (size_t)Cin * C * 9, &w);
                 h = R >= 16 ? pack_upconv(w, C, Cin, std, us, 1.0f) : pack_conv3(w, C, Cin, std, us, 1.0f);
             }
-            if (int rc = upload(c, h, &B.w1, T)) return rc;
+            if (int rc = upload_mfma(c, h, &B.w1, T)) return rc;
             snprintf(nm, sizeof nm, "%d_blur_1_w_kernel", R);
             NEED(P, nm, (size_t)C * 9, &w);
             h.assign(w, w + (size_t)C * 9);
@@ -560,7 +585,7 @@ int gsa_generator_commit(gsa_ctx* c) {
         if (int rc = get_std(c, nm, &std)) return rc;
         NEED(P, std::string(nm) + "_weight", (size_t)C * C * 9, &w);
         h = pack_conv3(w, C, C, std, us, 1.0f);
-        if (int rc = upload(c, h, &B.w2, T)) return rc;
+        if (int rc = upload_mfma(c, h, &B.w2, T)) return rc;
         for (int k = 0; k < 2; ++k) {
             snprintf(nm, sizeof nm, "%d_noise_%d_scale_factors", R, k + 1);
             NEED(P, nm, (size_t)C, &w); h.assign(w, w + C);
@@ -682,7 +707,7 @@ int gsa_decoder_commit(gsa_ctx* c) {
         NEED(P, std::string(nm) + ".weight", (size_t)d.F * d.I * 9, &w);
         NEED(P, std::string(nm) + ".bias", (size_t)d.F, &b);
         h = pack_conv3(w, d.F, d.I, 1.0f, false, 1.0f);
-        if (int rc = upload(c, h, &d.cvt_w, T)) return rc;
+        if (int rc = upload_mfma(c, h, &d.cvt_w, T)) return rc;
         h.assign(b, b + d.F);
         if (int rc = upload(c, h, &d.cvt_b, T)) return rc;
         snprintf(nm, sizeof nm, "cvt_block_%d.1", i);
@@ -693,14 +718,14 @@ int gsa_decoder_commit(gsa_ctx* c) {
             NEED(P, pf + ".0.weight", (size_t)d.cs * d.in_c * 9, &w);
             NEED(P, pf + ".0.bias", (size_t)d.cs, &b);
             h = (8 << i) >= 16 ? pack_upconv(w, d.cs, d.in_c, 1.0f, false, 1.0f) : pack_conv3(w, d.cs, d.in_c, 1.0f, false, 1.0f);
-            if (int rc = upload(c, h, &d.a_w, T)) return rc;
+            if (int rc = upload_mfma(c, h, &d.a_w, T)) return rc;
             h.assign(b, b + d.cs);
             if (int rc = upload(c, h, &d.a_b, T)) return rc;
             if (int rc = load_bn(c, pf + ".1", d.cs, &d.a_s, &d.a_rm, &d.a_beta)) return rc;
             NEED(P, pf + "." + std::to_string(second) + ".weight", (size_t)d.cs * d.cs * 9, &w);
             NEED(P, pf + "." + std::to_string(second) + ".bias", (size_t)d.cs, &b);
             h = pack_conv3(w, d.cs, d.cs, 1.0f, false, 1.0f);
-            if (int rc = upload(c, h, &d.b_w, T)) return rc;
+            if (int rc = upload_mfma(c, h, &d.b_w, T)) return rc;
             h.assign(b, b + d.cs);
             if (int rc = upload(c, h, &d.b_b, T)) return rc;
             if (int rc = load_bn(c, pf + "." + std::to_string(second + 1), d.cs, &d.b_s, &d.b_rm, &d.b_beta)) return rc;
@@ -710,7 +735,7 @@ int gsa_decoder_commit(gsa_ctx* c) {
                 NEED(P, sc + ".weight", (size_t)d.cs * d.in_c, &w);
                 NEED(P, sc + ".bias", (size_t)d.cs, &b);
                 h = pack_conv1(w, d.cs, d.in_c);
-                if (int rc = upload(c, h, &d.sc_w, T)) return rc;
+                if (int rc = upload_mfma(c, h, &d.sc_w, T)) return rc;
                 h.assign(b, b + d.cs);
                 if (int rc = upload(c, h, &d.sc_b, T)) return rc;
             } else if (i > 0) {
@@ -826,7 +851,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 if (!B.has_conv1) {
                     pp.src = c->constant; pp.src_per_sample = 0; pp.blur = nullptr;
                 } else {
-                    ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0;
+                    ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0; cp.bf16 = c->bf16;
                     cp.src0 = c->x2[l - 1]; cp.aff0 = c->aff2[l - 1]; cp.C0 = Cin;
                     cp.Hs = R / 2; cp.Ws = R / 2; cp.H = R; cp.W = R;
                     cp.wpk = B.w1; cp.Cout = C; cp.out = c->t_raw;
@@ -834,13 +859,13 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                         // Deconvolution 4x4 s2, or nearest-x2 + conv3x3 in sub-pixel form (same kernel)
                         snprintf(layer, sizeof layer, B.is_deconv ? "g.%d.deconv_1" : "g.%d.conv_1", R);
                         static thread_local char kn[96];
-                        snprintf(kn, sizeof kn, "void gsa::subpixel_mfma<%s, 0, false>(gsa::ConvParams)", subpixel_geom_name(R, R, C, n));
+                        snprintf(kn, sizeof kn, "void gsa::subpixel_mfma<%s, 0, false, %s>(gsa::ConvParams)", subpixel_geom_name(R, R, C, n), c->bf16 ? "true" : "false");
                         Launch lp(c, s, kn, layer, 2.0 * px * C * Cin * 4, 4.0 * (px / 4 * Cin + px * C));
                         HIP_TRY(launch_subpixel(cp, EPI_RAW, false, n, s));
                     } else {
                         cp.up = 1;
                         snprintf(layer, sizeof layer, "g.%d.conv_1", R);
-                        Launch lp(c, s, conv_kernel_name(R, C, n, EPI_RAW, false), layer, 2.0 * px * C * Cin * 9, 4.0 * (px / 4 * Cin + px * C));
+                        Launch lp(c, s, conv_kernel_name(c, R, C, n, EPI_RAW, false), layer, 2.0 * px * C * Cin * 9, 4.0 * (px / 4 * Cin + px * C));
                         HIP_TRY(launch_conv3x3(cp, EPI_RAW, false, n, s));
                     }
                     pp.src = c->t_raw; pp.src_per_sample = 1; pp.blur = B.blur;
@@ -850,14 +875,14 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 HIP_TRY(launch_post(pp, n, s));
                 prow = post_prow(R, R, C);
             } else {
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0; cp.bf16 = c->bf16;
                 cp.src0 = c->x1; cp.aff0 = c->aff1; cp.C0 = C;
                 cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
                 cp.wpk = B.w2; cp.Cout = C; cp.out = c->x2[l];
                 cp.noise = nz; cp.nscale = B.nscale[1]; cp.nbias = B.nbias[1]; cp.partials = c->partials; cp.acc = c->stat_acc;
                 snprintf(layer, sizeof layer, "g.%d.conv_2", R);
                 const bool ws = conv_uses_ws(cp, EPI_SYNTH, false, n);
-                Launch lp(c, s, ws ? "void gsa::conv3x3_ws<ws, 1>(gsa::ConvParams)" : conv_kernel_name(R, C, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
+                Launch lp(c, s, ws ? "void gsa::conv3x3_ws<ws, 1>(gsa::ConvParams)" : conv_kernel_name(c, R, C, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
                 prow = ws ? 0 : conv_stat_rows(R, R, C, n);
             }
@@ -898,20 +923,20 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
         const double px = N * R * R;
         if (wait_levels) HIP_TRY(hipStreamWaitEvent(s, c->ev_level[i], 0));   // generator feature i is ready
         {   // cvt_block: conv3x3+bias -> BN -> LeakyReLU (Dropout is identity at inference)
-            ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0;
+            ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0; cp.bf16 = c->bf16;
             cp.src0 = fsrc[i]; cp.aff0 = faff ? faff[i] : nullptr; cp.C0 = d.I;
             cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
             cp.wpk = d.cvt_w; cp.Cout = d.F; cp.out = c->cvt[i];
             cp.bias = d.cvt_b; cp.bn_s = d.cvt_s; cp.bn_rm = d.cvt_rm; cp.bn_beta = d.cvt_beta;
             snprintf(layer, sizeof layer, "d.cvt_%d", i);
-            Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(R, d.F, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
+            Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(c, R, d.F, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
             HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
         }
         if (!d.is_last) {
             const int R2 = 2 * R;
             const double px2 = 4 * px;
             {   // ResBlock conv a (+ fused 1x1 shortcut) on nearest-x2(concat(prev, cvt))
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0; cp.bf16 = c->bf16;
                 if (i > 0) { cp.src0 = c->prev[i - 1]; cp.C0 = d.F; cp.src1 = c->cvt[i]; cp.C1 = d.F; }
                 else { cp.src0 = c->cvt[i]; cp.C0 = d.F; }
                 cp.Hs = R; cp.Ws = R; cp.up = 1; cp.H = R2; cp.W = R2;
@@ -921,19 +946,19 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 snprintf(layer, sizeof layer, "d.main_%d.a", i);
                 if (R2 >= 16) {   // sub-pixel form: 4 taps per output instead of 9
                     static thread_local char kn[96];
-                    snprintf(kn, sizeof kn, "void gsa::subpixel_mfma<%s, 2, %s>(gsa::ConvParams)", subpixel_geom_name(R2, R2, d.cs, n), d.has_sc ? "true" : "false");
+                    snprintf(kn, sizeof kn, "void gsa::subpixel_mfma<%s, 2, %s, %s>(gsa::ConvParams)", subpixel_geom_name(R2, R2, d.cs, n), d.has_sc ? "true" : "false", c->bf16 ? "true" : "false");
                     Launch lp(c, s, kn, layer, 2.0 * px2 * d.cs * d.in_c * 4 + (d.has_sc ? 2.0 * px * d.cs * d.in_c : 0.0),
                               4.0 * (px * d.in_c + px2 * d.cs + (d.has_sc ? px * d.cs : 0.0)));
                     cp.up = 0;
                     HIP_TRY(launch_subpixel(cp, EPI_DEC, d.has_sc, n, s));
                 } else {
-                    Launch lp(c, s, conv_kernel_name(R2, d.cs, n, EPI_DEC, d.has_sc), layer,
+                    Launch lp(c, s, conv_kernel_name(c, R2, d.cs, n, EPI_DEC, d.has_sc), layer,
                               2.0 * px2 * d.cs * d.in_c * (9 + (d.has_sc ? 1 : 0)), 4.0 * (px * d.in_c + px2 * d.cs * (d.has_sc ? 2 : 1)));
                     HIP_TRY(launch_conv3x3(cp, EPI_DEC, d.has_sc, n, s));
                 }
             }
             {   // ResBlock conv b, + shortcut
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0; cp.bf16 = c->bf16;
                 cp.src0 = c->ya[i]; cp.C0 = d.cs;
                 cp.Hs = R2; cp.Ws = R2; cp.H = R2; cp.W = R2;
                 cp.wpk = d.b_w; cp.Cout = d.cs; cp.out = c->prev[i];
@@ -941,7 +966,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = R2 >= 16 ? 1 : 0; }   // sub-pixel conv a stores the shortcut at input resolution
                 else { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
-                Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(R2, d.cs, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
+                Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(c, R2, d.cs, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
             }
         } else {
@@ -1021,6 +1046,15 @@ int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const floa
 int gsa_set_overlap(gsa_ctx* c, int32_t levels) {
     if (!c) return GSA_ERR_INVALID;
     c->side_levels = levels < 0 ? 0 : levels;
+    return GSA_OK;
+}
+
+int gsa_set_precision(gsa_ctx* c, int32_t mode) {
+    if (!c) return GSA_ERR_INVALID;
+    if (mode != GSA_PREC_F32 && mode != GSA_PREC_BF16) return fail(c, GSA_ERR_INVALID, "gsa_set_precision: unknown mode");
+    if ((c->g_ready || c->d_ready) && mode != c->bf16)
+        return fail(c, GSA_ERR_STATE, "gsa_set_precision must precede gsa_generator_commit / gsa_decoder_commit (weights are packed per mode)");
+    c->bf16 = mode;
     return GSA_OK;
 }
 

@@ -40,6 +40,7 @@ struct ConvParams {
     int tiles_x, tiles_y, groups, total_tiles;   // filled by the launcher
     unsigned long long* stamps;   // diagnostic build (-DGSA_STAMP) only: per-phase cycle sums
     int dbg;                      // diagnostic build only: bit0 = stage pixel 0 everywhere (timing of a cache-resident input)
+    int bf16;                     // 1: bf16 MFMA mode -- wpk/wsc hold bf16 packs [..][tap][kq][16][4], operands rounded at staging
 };
 
 struct PostParams {

@@ -28,6 +28,10 @@
 namespace gsa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic build only (make stamp): s_memtime stamps at the phase boundaries of the conv
 // kernel, summed per phase into ConvParams::stamps.  No stamp executes in the product build.
@@ -118,7 +122,13 @@ __device__ __forceinline__ void load_pixel(f32x4 (&v)[4], const float* src, int 
 // AdaIN on the fly (zero padding stays zero), then the transposed 4x4 store.
 // HAS_AFF is wave-uniform; the coefficients of the sample were copied to LDS (saff, one float4
 // per input channel) at kernel start, so the write phase issues no global load.
-template <bool HAS_AFF>
+// BF (bf16 MFMA mode): the 16 values are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) AFTER the fp32 AdaIN and
+// stored in natural channel order, 32 bytes per pixel: the k slot of a 16x16x16 MFMA is 4 consecutive channels.
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+
+template <bool HAS_AFF, bool BF = false>
 __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const float4* saff, const TilePixel& tp) {
     const bool inside = tp.pix >= 0;
     float f[16] = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3],
@@ -131,6 +141,14 @@ __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const floa
             t = fmaf(t - a.x, a.y, a.z);
         }
         f[c] = inside ? t : 0.0f;
+    }
+    if (BF) {
+        if (tp.lds >= 0) {
+            u32x4* dst = reinterpret_cast<u32x4*>(sA + tp.lds);
+            dst[0] = u32x4{pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7])};
+            dst[1] = u32x4{pack_bf16(f[8], f[9]), pack_bf16(f[10], f[11]), pack_bf16(f[12], f[13]), pack_bf16(f[14], f[15])};
+        }
+        return;
     }
     if (tp.lds >= 0) {
         f32x4* dst = reinterpret_cast<f32x4*>(sA + tp.lds);
@@ -153,19 +171,25 @@ __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const floa
 // layers.)
 struct WorkTile { int n, g, y0, x0, row; };   // row = tile index inside the image
 
-template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC>
+//
+// BF = bf16 MFMA mode (BASELINE config 5): operands are rounded to bf16 when they are staged (inputs after
+// the fp32 AdaIN, weights on the host), one v_mfma_f32_16x16x16_bf16 per (tap, 16-channel block) replaces four
+// fp32 MFMAs, accumulation / epilogue / statistics stay fp32.  LDS offsets are in 4-byte slots in both modes:
+// a staged pixel is PX slots, a (tap, 16 couts, 16 channels) weight chunk TS slots.
+template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC, bool BF>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
     constexpr int NW = WM * WN, NTHR = 64 * NW;
     constexpr int PW = TW / 4, MT = (TH / 4) * PW / WM;
     constexpr int LH = TH + 2, LW = TW + 2;
-    constexpr int RS = LW * 16 + 8;              // floats; RS % 16 == 8
+    constexpr int PX = BF ? 8 : 16, TS = BF ? 128 : 256, KQ = BF ? 2 : 4;
+    constexpr int RS = LW * PX + (BF ? 4 : 8);   // slots; fp32: RS % 16 == 8 (conflict-free ds_read_b128)
     constexpr int Q = NT * WN;                   // 16-channel output groups per workgroup
     constexpr int COUT_T = 16 * Q;
-    constexpr int SEG = 9 * 256;                 // weight floats per (16 couts, 16-channel block)
-    constexpr int NB4 = Q * SEG / 4;             // float4s of weights per block
+    constexpr int SEG = 9 * TS;                  // weight slots per (16 couts, 16-channel block)
+    constexpr int NB4 = Q * SEG / 4;             // 16-byte pieces of weights per block
     constexpr int AIT = (LH * LW + NTHR - 1) / NTHR;
     constexpr int BIT = (NB4 + NTHR - 1) / NTHR;
-    constexpr int SIT = (Q * 64 + NTHR - 1) / NTHR;   // shortcut weights: Q*256 floats
+    constexpr int SIT = (Q * TS / 4 + NTHR - 1) / NTHR;   // shortcut weights: Q*TS slots
     constexpr int FIT = (512 + NTHR - 1) / NTHR;      // AdaIN table: up to 512 input channels
     // DB: double-buffered LDS images for the narrow channel tiles (<= 32 output channels): the LDS
     // write of item i+1 no longer has to wait for the readers of item i, so it sits in front of
@@ -177,7 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
     float* sA = smem;                            // [NBUF][LH*RS]
     float* sB = sA + NBUF * LH * RS;             // [NBUF][q][tap][ci][16][cg]
     float* sS = sB + NBUF * Q * SEG;             // SC: [q][ci][16][cg]
-    f32x4* sAff = reinterpret_cast<f32x4*>(sS + (SC ? Q * 256 : 0));   // [C0] (mean, A, B, -)
+    f32x4* sAff = reinterpret_cast<f32x4*>(sS + (SC ? Q * TS : 0));   // [C0] (mean, A, B, -)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,7 +233,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
             const int gy = t.y0 - 1 + ly, gx = t.x0 - 1 + lx;
             const bool stage = idx < LH * LW;
             const bool inside = stage && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            tp[it].lds = stage ? ly * RS + lx * 16 : -1;
+            tp[it].lds = stage ? ly * RS + lx * PX : -1;
             tp[it].pix = inside ? (t.n * p.Hs + (gy >> p.up)) * p.Ws + (gx >> p.up) : -1;
 #ifdef GSA_DBG_HOOKS
             if ((p.dbg & 1) && inside) tp[it].pix = lx & 1;      // timing-only: cache-resident input
@@ -221,10 +245,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
-        abase[mt] = (pr * 4 + (i16 >> 2)) * RS + (pc * 4 + (i16 & 3)) * 16 + kq * 4;
+        abase[mt] = (pr * 4 + (i16 >> 2)) * RS + (pc * 4 + (i16 & 3)) * PX + kq * KQ;
     }
-    const int bbase = wn * NT * SEG + (kq * 16 + i16) * 4;
-    const int sbase = wn * NT * 256 + (kq * 16 + i16) * 4;
+    const int bbase = wn * NT * SEG + (kq * 16 + i16) * KQ;
+    const int sbase = wn * NT * TS + (kq * 16 + i16) * KQ;
 
     f32x4 acc[MT][NT];
     f32x4 accs[SC ? MT : 1][SC ? NT : 1];
@@ -259,9 +283,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         if (SC) {
 #pragma unroll
             for (int j = 0; j < SIT; ++j) {
-                const int i = min(tid + j * NTHR, Q * 64 - 1);
-                const int q = i / 64, r = i % 64;
-                rs[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)(t.g * Q + q) * nblk + cb) * 256)[r];
+                const int i = min(tid + j * NTHR, Q * TS / 4 - 1);
+                const int q = i / (TS / 4), r = i % (TS / 4);
+                rs[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)(t.g * Q + q) * nblk + cb) * TS)[r];
             }
         }
         if (has_aff) {     // AdaIN table of the item's sample (copied to LDS when the sample changes)
@@ -278,16 +302,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         float* a_img = sA + buf * (LH * RS);
         if (cb < nblk0 && has_aff) {      // wave-uniform
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<true>(a_img, ra[it], reinterpret_cast<const float4*>(sAff) + cb * 16, tp[it]);
+            for (int it = 0; it < AIT; ++it) store_pixel<true, BF>(a_img, ra[it], reinterpret_cast<const float4*>(sAff) + cb * 16, tp[it]);
         } else {
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<false>(a_img, ra[it], reinterpret_cast<const float4*>(sAff), tp[it]);
+            for (int it = 0; it < AIT; ++it) store_pixel<false, BF>(a_img, ra[it], reinterpret_cast<const float4*>(sAff), tp[it]);
         }
 #pragma unroll
         for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * (Q * SEG))[min(tid + j * NTHR, NB4 - 1)] = rb[j];
         if (SC) {
 #pragma unroll
-            for (int j = 0; j < SIT; ++j) reinterpret_cast<f32x4*>(sS)[min(tid + j * NTHR, Q * 64 - 1)] = rs[j];
+            for (int j = 0; j < SIT; ++j) reinterpret_cast<f32x4*>(sS)[min(tid + j * NTHR, Q * TS / 4 - 1)] = rs[j];
         }
     };
 
@@ -387,8 +411,38 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
             };
 
     auto mfma_item = [&](int buf) {
+#ifdef GSA_DBG_HOOKS
+        if (p.dbg & 16) return;      // timing-only: no MFMA phase
+#endif
         const float* a_img = sA + buf * (LH * RS);
         const float* b_img = sB + buf * (Q * SEG);
+        if constexpr (BF) {
+            // ---- bf16: one 16x16x16 MFMA per (tap, patch, cout group); k slot kq = channels 4kq..4kq+3
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = (tap / 3) * RS + (tap % 3) * PX;
+                s16x4 a[MT], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const s16x4*>(a_img + abase[mt] + toff);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const s16x4*>(b_img + bbase + nt * SEG + tap * TS);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                if (SC && tap == 4) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const s16x4 bs = *reinterpret_cast<const s16x4*>(sS + sbase + nt * TS);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            accs[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[mt], bs, accs[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
         // ---- MFMA: K order (tap, cg, ci) inside the block
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -452,6 +506,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         __syncthreads();
         for (int it = 0; it < total_items; ++it) {
             const bool has_next = it + 1 < total_items;
+#ifdef GSA_DBG_HOOKS
+            if (!(p.dbg & 8))        // timing-only: no LDS staging writes in the steady state
+#endif
             if (has_next) write_item(cbr, tpr, (it + 1) & 1);  // item it+1: registers -> the other LDS buffer
             WorkTile t2; int cb2;
             item_at(it + 2, t2, cb2);
@@ -516,6 +573,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
             n_aff = tn.n;
             __syncthreads();
         }
+#ifdef GSA_DBG_HOOKS
+        if (!(p.dbg & 8))
+#endif
         write_item(cb2, tpn);
         __syncthreads();
         tc = tn; w = w2; cb = cb2;
@@ -875,16 +935,17 @@ __global__ __launch_bounds__(256 + 64 * kWsLoaderWaves) void conv3x3_ws(ConvPara
 // 4x4 stride-2 kernel: 2.25x fewer MACs than 9 taps on the upsampled image).
 // A 16x16 output tile splits into 4 parity classes (oy&1, ox&1); each is a 2x2-tap convolution
 // over the 10x10 input tile with its own weights.  One wave per class, 4 patches of 4x4 outputs.
-template <int NT, int EPI, bool SC>
+template <int NT, int EPI, bool SC, bool BF>
 __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
-    constexpr int LH = 10, LW = 10, RS = LW * 16 + 8;
-    constexpr int COUT_T = 16 * NT, SEG = 16 * 256, NB4 = NT * SEG / 4, BIT = (NB4 + 255) / 256;
-    constexpr int SIT = (NT * 64 + 255) / 256;
+    constexpr int PX = BF ? 8 : 16, TS = BF ? 128 : 256, KQ = BF ? 2 : 4;     // 4-byte slots, as in conv3x3_mfma
+    constexpr int LH = 10, LW = 10, RS = LW * PX + (BF ? 4 : 8);
+    constexpr int COUT_T = 16 * NT, SEG = 16 * TS, NB4 = NT * SEG / 4, BIT = (NB4 + 255) / 256;
+    constexpr int SIT = (NT * TS / 4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sB = sA + LH * RS;                     // [q][tap16][ci][16][cg]
     float* sS = sB + NT * SEG;                    // SC: [q][ci][16][cg]
-    float4* sAff = reinterpret_cast<float4*>(sS + (SC ? NT * 256 : 0));
+    float4* sAff = reinterpret_cast<float4*>(sS + (SC ? NT * TS : 0));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int py = wave >> 1, px = wave & 1;
@@ -899,7 +960,7 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
         const int gy = iy0 + ly, gx = ix0 + lx;
         const bool stage = tid < LH * LW;
         const bool inside = stage && gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws;
-        tp.lds = stage ? ly * RS + lx * 16 : -1;
+        tp.lds = stage ? ly * RS + lx * PX : -1;
         tp.pix = inside ? (n * p.Hs + gy) * p.Ws + gx : -1;
 #ifdef GSA_DBG_HOOKS
         if ((p.dbg & 1) && inside) tp.pix = lx & 1;              // timing-only: cache-resident input
@@ -908,13 +969,13 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
     int abase[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
-        abase[mt] = ((mt >> 1) * 4 + (i16 >> 2) + 1) * RS + ((mt & 1) * 4 + (i16 & 3) + 1) * 16 + kq * 4;
-    const int bbase = (kq * 16 + i16) * 4;
+        abase[mt] = ((mt >> 1) * 4 + (i16 >> 2) + 1) * RS + ((mt & 1) * 4 + (i16 & 3) + 1) * PX + kq * KQ;
+    const int bbase = (kq * 16 + i16) * KQ;
     // fused 1x1 shortcut: on a nearest-upsampled input it is the same value for the 4 sub-pixels of
     // an input pixel, so it is computed ONCE per input pixel and stored at the input resolution
     // (the consumer reads it with resid_up).  The 8x8 input pixels of the tile are 4 patches; wave w
     // takes patch w (A operand = the offset-(0,0) tap of that patch).
-    const int asc = ((wave >> 1) * 4 + (i16 >> 2) + 1) * RS + ((wave & 1) * 4 + (i16 & 3) + 1) * 16 + kq * 4;
+    const int asc = ((wave >> 1) * 4 + (i16 >> 2) + 1) * RS + ((wave & 1) * 4 + (i16 & 3) + 1) * PX + kq * KQ;
     f32x4 acc[4][NT];
     f32x4 accs[SC ? NT : 1];
 #pragma unroll
@@ -943,20 +1004,20 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
         if (SC) {
 #pragma unroll
             for (int j = 0; j < SIT; ++j) {
-                const int i = min(tid + j * 256, NT * 64 - 1);
-                const int q = i / 64, r = i % 64;
-                rs[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)(g * NT + q) * nblk + cb) * 256)[r];
+                const int i = min(tid + j * 256, NT * TS / 4 - 1);
+                const int q = i / (TS / 4), r = i % (TS / 4);
+                rs[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)(g * NT + q) * nblk + cb) * TS)[r];
             }
         }
     };
     auto write_block = [&](int cb) {
-        if (cb < nblk0 && p.aff0) store_pixel<true>(sA, ra, sAff + cb * 16, tp);
-        else store_pixel<false>(sA, ra, sAff, tp);
+        if (cb < nblk0 && p.aff0) store_pixel<true, BF>(sA, ra, sAff + cb * 16, tp);
+        else store_pixel<false, BF>(sA, ra, sAff, tp);
 #pragma unroll
         for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB)[min(tid + j * 256, NB4 - 1)] = rb[j];
         if (SC) {
 #pragma unroll
-            for (int j = 0; j < SIT; ++j) reinterpret_cast<f32x4*>(sS)[min(tid + j * 256, NT * 64 - 1)] = rs[j];
+            for (int j = 0; j < SIT; ++j) reinterpret_cast<f32x4*>(sS)[min(tid + j * 256, NT * TS / 4 - 1)] = rs[j];
         }
     };
     load_block(0);
@@ -972,6 +1033,9 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
         __builtin_amdgcn_sched_barrier(0);
         // valid taps of this parity class, ascending ky then kx:
         //   py==0: ky=1 (dy 0), ky=3 (dy -1);   py==1: ky=0 (dy +1), ky=2 (dy 0)
+#ifdef GSA_DBG_HOOKS
+        if (!(p.dbg & 16)) {
+#endif
 #pragma unroll
         for (int jy = 0; jy < 2; ++jy) {
             const int ky = (py ? 0 : 1) + 2 * jy;
@@ -980,8 +1044,20 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
             for (int jx = 0; jx < 2; ++jx) {
                 const int kx = (px ? 0 : 1) + 2 * jx;
                 const int dx = px ? (1 - jx) : -jx;
-                const int toff = dy * RS + dx * 16;
+                const int toff = dy * RS + dx * PX;
                 const int tap = ky * 4 + kx;
+                if constexpr (BF) {
+                    s16x4 a[4], b[NT];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const s16x4*>(sA + abase[mt] + toff);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const s16x4*>(sB + bbase + nt * SEG + tap * TS);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                } else {
                 f32x4 a[4], b[NT];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(sA + abase[mt] + toff);
@@ -994,9 +1070,18 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
+                }
             }
         }
-        if (SC) {   // natural channel order: block, then 4 k-slots of 4 channels
+#ifdef GSA_DBG_HOOKS
+        }
+#endif
+        if constexpr (SC && BF) {
+            const s16x4 as = *reinterpret_cast<const s16x4*>(sA + asc);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                accs[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(as, *reinterpret_cast<const s16x4*>(sS + bbase + nt * TS), accs[nt], 0, 0, 0);
+        } else if constexpr (SC) {   // natural channel order: block, then 4 k-slots of 4 channels
             const f32x4 as = *reinterpret_cast<const f32x4*>(sA + asc);
             f32x4 bs[NT];
 #pragma unroll
@@ -1010,6 +1095,9 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
         __builtin_amdgcn_sched_barrier(0);
         if (cb + 1 < nblk) {
             __syncthreads();
+#ifdef GSA_DBG_HOOKS
+            if (!(p.dbg & 8))
+#endif
             write_block(cb + 1);
             __syncthreads();
         }
@@ -1497,14 +1585,15 @@ const char* conv_geom_name(int H, int W, int Cout, int n) {
     return buf;
 }
 
-template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC>
+template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC, bool BF>
 static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int Q = NT * WN, COUT_T = 16 * Q;
-    constexpr int RS = (TW + 2) * 16 + 8;
+    constexpr int TS = BF ? 128 : 256;
+    constexpr int RS = (TW + 2) * (BF ? 8 : 16) + (BF ? 4 : 8);
     if (p.C0 > 512 && p.aff0) return hipErrorInvalidValue;   // AdaIN table registers sized for <= 512 channels
     constexpr int NBUF = (Q <= 2 && !SC && TH == 16) ? 2 : 1;   // must match the kernel's DB
-    const size_t lds = sizeof(float) * (NBUF * ((TH + 2) * RS + Q * 9 * 256) + (SC ? Q * 256 : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
-    auto kern = conv3x3_mfma<TH, TW, WM, WN, NT, EPI, SC>;
+    const size_t lds = sizeof(float) * (NBUF * ((TH + 2) * RS + Q * 9 * TS) + (SC ? Q * TS : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
+    auto kern = conv3x3_mfma<TH, TW, WM, WN, NT, EPI, SC, BF>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1536,18 +1625,24 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int TH, int TW, int WM, int WN, int NT>
-static hipError_t launch_conv_e(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
+template <int TH, int TW, int WM, int WN, int NT, bool BF>
+static hipError_t launch_conv_b(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     if (sc) {
         if (epi != EPI_DEC) return hipErrorInvalidValue;
-        return launch_conv_t<TH, TW, WM, WN, NT, EPI_DEC, true>(p, n, s);
+        return launch_conv_t<TH, TW, WM, WN, NT, EPI_DEC, true, BF>(p, n, s);
     }
     switch (epi) {
-        case EPI_RAW: return launch_conv_t<TH, TW, WM, WN, NT, EPI_RAW, false>(p, n, s);
-        case EPI_SYNTH: return launch_conv_t<TH, TW, WM, WN, NT, EPI_SYNTH, false>(p, n, s);
-        case EPI_DEC: return launch_conv_t<TH, TW, WM, WN, NT, EPI_DEC, false>(p, n, s);
+        case EPI_RAW: return launch_conv_t<TH, TW, WM, WN, NT, EPI_RAW, false, BF>(p, n, s);
+        case EPI_SYNTH: return launch_conv_t<TH, TW, WM, WN, NT, EPI_SYNTH, false, BF>(p, n, s);
+        case EPI_DEC: return launch_conv_t<TH, TW, WM, WN, NT, EPI_DEC, false, BF>(p, n, s);
     }
     return hipErrorInvalidValue;
+}
+
+template <int TH, int TW, int WM, int WN, int NT>
+static hipError_t launch_conv_e(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
+    return p.bf16 ? launch_conv_b<TH, TW, WM, WN, NT, true>(p, epi, sc, n, s)
+                  : launch_conv_b<TH, TW, WM, WN, NT, false>(p, epi, sc, n, s);
 }
 
 template <int NT, int EPI>
@@ -1602,7 +1697,7 @@ hipError_t launch_conv3x3_ws(const ConvParams& p, int epi, int n, hipStream_t s)
 
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     if (p.H != p.W || (p.H & (p.H - 1)) || p.H < 4 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
-    if (conv_uses_ws(p, epi, sc, n)) return launch_conv3x3_ws(p, epi, n, s);
+    if (!p.bf16 && conv_uses_ws(p, epi, sc, n)) return launch_conv3x3_ws(p, epi, n, s);
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
 #define GSA_GEOM(TH, WM, WN, NT) \
     if (c.th == TH && c.wm == WM && c.wn == WN && c.nt == NT) return launch_conv_e<TH, TH, WM, WN, NT>(p, epi, sc, n, s);
@@ -1613,11 +1708,11 @@ hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStrea
     return hipErrorInvalidValue;
 }
 
-template <int NT, int EPI, bool SC>
+template <int NT, int EPI, bool SC, bool BF>
 static hipError_t launch_subpixel_t(const ConvParams& p, int n, hipStream_t s) {
-    constexpr int COUT_T = 16 * NT;
-    const size_t lds = sizeof(float) * (10 * (10 * 16 + 8) + NT * 16 * 256 + (SC ? NT * 256 : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
-    auto kern = subpixel_mfma<NT, EPI, SC>;
+    constexpr int COUT_T = 16 * NT, TS = BF ? 128 : 256;
+    const size_t lds = sizeof(float) * (10 * (10 * (BF ? 8 : 16) + (BF ? 4 : 8)) + NT * 16 * TS + (SC ? NT * TS : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
+    auto kern = subpixel_mfma<NT, EPI, SC, BF>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1651,10 +1746,16 @@ hipError_t launch_subpixel(const ConvParams& p, int epi, bool sc, int n, hipStre
     if (sc && epi != EPI_DEC) return hipErrorInvalidValue;
     const int ct = subpixel_cout_tile(p.H, p.W, p.Cout, n);
 #define GSA_SUB(NT) \
-    if (ct == 16 * NT) { \
-        if (sc) return launch_subpixel_t<NT, EPI_DEC, true>(p, n, s); \
-        if (epi == EPI_DEC) return launch_subpixel_t<NT, EPI_DEC, false>(p, n, s); \
-        if (epi == EPI_RAW) return launch_subpixel_t<NT, EPI_RAW, false>(p, n, s); \
+    if (ct == 16 * NT && !p.bf16) { \
+        if (sc) return launch_subpixel_t<NT, EPI_DEC, true, false>(p, n, s); \
+        if (epi == EPI_DEC) return launch_subpixel_t<NT, EPI_DEC, false, false>(p, n, s); \
+        if (epi == EPI_RAW) return launch_subpixel_t<NT, EPI_RAW, false, false>(p, n, s); \
+        return hipErrorInvalidValue; \
+    } \
+    if (ct == 16 * NT && p.bf16) { \
+        if (sc) return launch_subpixel_t<NT, EPI_DEC, true, true>(p, n, s); \
+        if (epi == EPI_DEC) return launch_subpixel_t<NT, EPI_DEC, false, true>(p, n, s); \
+        if (epi == EPI_RAW) return launch_subpixel_t<NT, EPI_RAW, false, true>(p, n, s); \
         return hipErrorInvalidValue; \
     }
     GSA_SUB(4) GSA_SUB(2) GSA_SUB(1)

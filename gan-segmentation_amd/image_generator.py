@@ -22,7 +22,7 @@ from .networks_stylegan import Generator
 
 
 class ImageGenerator:
-    def __init__(self, gpu_ids, gan_dir, gan="ffhq", batch_size=4, return_latents=False, seed=0):
+    def __init__(self, gpu_ids, gan_dir, gan="ffhq", batch_size=4, return_latents=False, seed=0, precision="fp32"):
         max_res_log2_dict = _weights.GAN_MAX_RES_LOG2
         self.max_res_log2 = max_res_log2_dict[gan]
         self.latent_size = 512
@@ -36,6 +36,7 @@ class ImageGenerator:
             raise RuntimeError("one process drives one GPU; shard batches across ranks with "
                                "gan_segmentation_amd.dist (one process per GPU over RCCL)")
         self.ctx = gpu_ids
+        self.precision = precision
         self.cfg = self._get_config(max_res_log2=self.max_res_log2)
         self.netG = self._get_G(self.cfg, gpu_ids[0])
         stylegan_name = "stylegan-%s.params" % gan
@@ -47,7 +48,7 @@ class ImageGenerator:
 
     @classmethod
     def from_params(cls, gcfg, gparams, dcfg=None, dparams=None, gpu_ids=(0,), batch_size=4,
-                    return_latents=False, seed=0):
+                    return_latents=False, seed=0, precision="fp32"):
         """Build from in-memory weights (tests, benchmarks: no pretrained files exist here)."""
         self = cls.__new__(cls)
         self.max_res_log2 = gcfg["max_res_log2"]
@@ -56,7 +57,8 @@ class ImageGenerator:
         self.batch_size = batch_size
         self.ctx = list(gpu_ids)
         self.cfg = dict(gcfg)
-        self.netG = Generator(self.cfg, device=self.ctx[0])
+        self.precision = precision
+        self.netG = Generator(self.cfg, device=self.ctx[0], precision=precision)
         self.netG.load_parameters(gparams)
         self._decoder = None
         if dcfg is not None:
@@ -67,7 +69,7 @@ class ImageGenerator:
         return self
 
     def _get_G(self, config, device):
-        return Generator(config, device=device)
+        return Generator(config, device=device, precision=self.precision)
 
     def _get_config(self, max_res_log2=9):
         return _weights.generator_config(max_res_log2)  # reference image_generator.py:46-74
@@ -76,8 +78,11 @@ class ImageGenerator:
         """Put a decoder on the same GPU so ``generate_batch`` can run the fused path."""
         dec = dparams if isinstance(dparams, Decoder) else None
         if dec is None:
-            dec = Decoder(dcfg, 1, device=self.ctx[0])
+            dec = Decoder(dcfg, 1, device=self.ctx[0], precision=self.precision)
             dec.load_parameters(dparams)
+        if dec._model is not self.netG._model:
+            raise RuntimeError("the decoder lives on another device or precision than the generator "
+                               "(%s vs %s)" % (dec.precision, self.precision))
         self._decoder = dec
         return dec
 

@@ -33,13 +33,14 @@ def generate(cfg, limit=None, workers=None):
     gpu = gpu_ids[local_rank % len(gpu_ids)] if world == 1 and gpu_ids else local_rank
     n_generate = cfg.get("GENERATE_NUM", 10000) if limit is None else limit
     batch = cfg["GAN_BATCH_SIZE_PER_GPU"]
+    precision = cfg.get("PRECISION", "fp32")   # additive key: "bf16" = bf16 MFMA operands (BASELINE config 5)
 
     solver = SegSolver(GAN_MAX_RES_LOG2[gan], os.path.join(root_dir, "data"), os.path.join(root_dir, "checkpoints"),
-                       gpu_ids=[gpu], keep_weights=False)
+                       gpu_ids=[gpu], keep_weights=False, precision=precision)
     if not solver.is_trained:
         print("train Decoder first!")   # reference main.py:82-84
         return -1
-    netG = ImageGenerator(gpu_ids=[gpu], gan_dir=gan_dir, gan=gan, batch_size=batch)
+    netG = ImageGenerator(gpu_ids=[gpu], gan_dir=gan_dir, gan=gan, batch_size=batch, precision=precision)
     netG.attach_decoder(solver.cfg, solver.net)
     dst_dir = os.path.join(root_dir, "dataset", "train_generated")
     os.makedirs(dst_dir, exist_ok=True)

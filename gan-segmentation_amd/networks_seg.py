@@ -13,13 +13,14 @@ from ._runtime import DeviceModel, current_stream_ptr, to_device_f32
 
 
 class Decoder:
-    def __init__(self, cfg, num_devices=1, device=0, **kwargs):
+    def __init__(self, cfg, num_devices=1, device=0, precision="fp32", **kwargs):
         self.cfg = dict(cfg)
         for key in ("features", "in_channels", "start_res", "use_bn", "use_sync_bn", "use_dropout"):
             if key not in self.cfg:
                 raise KeyError("Decoder cfg is missing %r" % key)  # reference :54-62
         self._num_devices = num_devices
-        self._model = DeviceModel.get(device)
+        self.precision = precision
+        self._model = DeviceModel.get(device, precision)
         self._model.ctx.decoder_init(self.cfg)
         self._model.decoder_cfg = self.cfg
         self._model.invalidate_workspace()

@@ -16,7 +16,8 @@ from .networks_seg import Decoder
 
 
 class SegSolver:
-    def __init__(self, max_res_log2, path_to_data, checkpoints_dir, gpu_ids, keep_weights=True, in_channels=None):
+    def __init__(self, max_res_log2, path_to_data, checkpoints_dir, gpu_ids, keep_weights=True, in_channels=None,
+                 precision="fp32"):
         self.path_to_data = path_to_data
         self.checkpoints_dir = checkpoints_dir
         self.keep_weights = keep_weights
@@ -27,6 +28,7 @@ class SegSolver:
         if len(gpu_ids) > 1:
             raise RuntimeError("one process drives one GPU; shard across ranks with gan_segmentation_amd.dist")
         self.ctx = gpu_ids
+        self.precision = precision
         self.is_trained = False
         self.params_file = None
         self.cfg = self.get_config(max_res_log2=max_res_log2, in_channels=in_channels)
@@ -39,7 +41,7 @@ class SegSolver:
     def init_net(self):
         # the reference also Xavier-initialises here (:38-46); without a checkpoint this solver
         # is simply "not trained" and predict() refuses to run
-        return Decoder(self.cfg, num_devices=len(self.ctx), device=self.ctx[0])
+        return Decoder(self.cfg, num_devices=len(self.ctx), device=self.ctx[0], precision=self.precision)
 
     def load(self):
         """Load the first ``*.params`` file of the checkpoints dir (reference :339-349)."""

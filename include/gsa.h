@@ -128,6 +128,16 @@ int gsa_generate(gsa_ctx* ctx, void* stream, int32_t n, const float* z,
  * serialized roofline pass so that kernel durations are not stretched by concurrent kernels). */
 int gsa_set_overlap(gsa_ctx* ctx, int32_t levels);
 
+/* Arithmetic of the MFMA convolutions (BASELINE.json configs[4], "bf16 MFMA"; the reference itself is fp32
+ * only, networks_stylegan.py / networks_seg.py use MXNet's default dtype).
+ *   GSA_PREC_F32  (default) exact-fp32 MFMA, the canonical bit-exact path;
+ *   GSA_PREC_BF16 conv / deconv inputs (after the fp32 AdaIN) and weights are rounded to bf16 (RNE) and
+ *                 multiplied on v_mfma_f32_16x16x16_bf16; accumulation, bias/BN/LeakyReLU, noise, instance-norm
+ *                 statistics, mapping network, toRGB and the final 32->classes conv stay fp32.
+ * Must be called before the commits (weights are packed per mode): GSA_ERR_STATE otherwise. */
+typedef enum { GSA_PREC_F32 = 0, GSA_PREC_BF16 = 1 } gsa_precision;
+int gsa_set_precision(gsa_ctx* ctx, int32_t mode);
+
 /* --- measurement hooks (bench.py) ------------------------------------------------------ */
 
 /* When enabled every kernel launch is bracketed by hipEvents on the launch stream. */

@@ -35,8 +35,10 @@ def api():
 class Oracle:
     """Generator + decoder on host memory in the canonical fp32 order."""
 
-    def __init__(self, gcfg=None, gparams=None, dcfg=None, dparams=None):
+    def __init__(self, gcfg=None, gparams=None, dcfg=None, dparams=None, precision="fp32"):
         self.ctx = _lib.Context(api(), 0)
+        if precision != "fp32":
+            self.ctx.set_precision(precision)      # operands of the MFMA convolutions rounded to bf16
         self.gcfg, self.dcfg = gcfg, dcfg
         if gcfg is not None:
             self.ctx.generator_init(gcfg)

@@ -46,6 +46,7 @@
 #define GSAO_API __attribute__((visibility("default")))
 
 enum { GSA_OK = 0, GSA_ERR_INVALID = -1, GSA_ERR_STATE = -2, GSA_ERR_MISSING_PARAM = -3, GSA_ERR_NOMEM = -5 };
+enum { GSA_PREC_F32 = 0, GSA_PREC_BF16 = 1 };
 
 typedef struct {
     int32_t max_res_log2, fmap_base;
@@ -115,6 +116,7 @@ typedef struct gsao_ctx {
     gen_block blk[MAX_LEVELS];
     float* rgb_w; float* rgb_b;  /* [ch][C] effective, bias */
     /* decoder */
+    int bf16;               /* gsao_set_precision: operands of the MFMA convolutions rounded to bf16 */
     int d_init, d_ready;
     int d_n, d_s0, d_bn, d_feat[MAX_LEVELS + 1], d_inch[MAX_LEVELS];
     param_table dp;
@@ -287,6 +289,12 @@ GSAO_API void gsao_destroy(gsao_ctx* c) {
 }
 
 GSAO_API const char* gsao_last_error(const gsao_ctx* c) { return c ? c->err : g_err; }
+GSAO_API int gsao_set_precision(gsao_ctx* c, int32_t mode) {
+    if (!c || (mode != GSA_PREC_F32 && mode != GSA_PREC_BF16)) return GSA_ERR_INVALID;
+    c->bf16 = mode;
+    return GSA_OK;
+}
+
 GSAO_API const char* gsao_version(void) { return "gsa-oracle 0.1 (canonical fp32 CPU restatement)"; }
 
 /* ---------------------------------------------------------------- generator setup */
@@ -500,10 +508,26 @@ static void dense(const float* x, const float* W, const float* b, int J, int K, 
 #define PX 4
 #define OC 16
 
+/* bf16 mode (include/gsa.h gsa_set_precision): conv inputs (after AdaIN) and weights are rounded to bf16,
+ * round-to-nearest-even -- what v_cvt_pk_bf16_f32 and the host packer of the HIP library do.  Products of
+ * two bf16 are exact in fp32; the accumulation below stays the canonical fp32 chain, while the matrix core
+ * adds its 16 products per instruction in an order/alignment of its own (tools/probe/), so parity with the
+ * HIP path in this mode is a tolerance, not bit equality. */
+static inline float bf16r(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return f;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+#define OPND(v) (bf ? bf16r(v) : (v))
+
 /* 3x3 conv, pad 1, NHWC.  in: [Hs][Ws][Cin] (already affine-applied); when up!=0 the
  * logical input is the nearest-x2 upsample of `in` (UpSampling, reference :308-315).
  * out: raw accumulators [H][W][Cout], H = Hs<<up. */
-static void conv3x3(const float* in, int Hs, int Ws, int Cin, int up, const float* Wp, int Cout, float* out) {
+static void conv3x3(const float* in, int Hs, int Ws, int Cin, int up, const float* Wp, int Cout, float* out, int bf) {
     const int H = Hs << up, W = Ws << up;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int y = 0; y < H; ++y)
@@ -519,11 +543,14 @@ static void conv3x3(const float* in, int Hs, int Ws, int Cin, int up, const floa
                         if (yy < 0 || yy >= H) continue;
                         for (int kx = 0; kx < 3; ++kx)
                             for (int ci = 0; ci < CB; ++ci) {
-                                const float* wrow = Wp + (((size_t)cb * 9 + ky * 3 + kx) * CB + ci) * Cout + o0;
+                                const float* wsrc = Wp + (((size_t)cb * 9 + ky * 3 + kx) * CB + ci) * Cout + o0;
+                                float wrow[OC];
+                                for (int o = 0; o < on; ++o) wrow[o] = OPND(wsrc[o]);
+                                for (int o = on; o < OC; ++o) wrow[o] = 0.0f;
                                 for (int p = 0; p < PX; ++p) {
                                     const int xx = x0 + p + kx - 1;
                                     if (xx < 0 || xx >= W) continue;
-                                    const float a = in[((size_t)(yy >> up) * Ws + (xx >> up)) * Cin + cb * CB + ci];
+                                    const float a = OPND(in[((size_t)(yy >> up) * Ws + (xx >> up)) * Cin + cb * CB + ci]);
                                     if (on == OC) {
                                         for (int o = 0; o < OC; ++o) acc[p][o] = fmaf(a, wrow[o], acc[p][o]);
                                     } else {
@@ -540,7 +567,7 @@ static void conv3x3(const float* in, int Hs, int Ws, int Cin, int up, const floa
 /* Deconvolution k4 s2 p1 (reference networks_stylegan.py:460-476, A.3):
  * out[oy][ox][o] = sum in[iy][ix][i] * W[i][o][ky][kx] over oy = 2*iy - 1 + ky.
  * Canonical order: 16-channel block, then valid ky ascending, valid kx ascending, channel. */
-static void deconv4x4s2(const float* in, int Hs, int Ws, int Cin, const float* Wd, int Cout, float* out) {
+static void deconv4x4s2(const float* in, int Hs, int Ws, int Cin, const float* Wd, int Cout, float* out, int bf) {
     const int H = Hs * 2, W = Ws * 2;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int oy = 0; oy < H; ++oy)
@@ -557,9 +584,9 @@ static void deconv4x4s2(const float* in, int Hs, int Ws, int Cin, const float* W
                             const int ix = (ox + 1 - kx) / 2;
                             if (ox + 1 - kx < 0 || ix >= Ws) continue;
                             for (int ci = 0; ci < CB; ++ci) {
-                                const float a = in[((size_t)iy * Ws + ix) * Cin + cb * CB + ci];
+                                const float a = OPND(in[((size_t)iy * Ws + ix) * Cin + cb * CB + ci]);
                                 const float* wrow = Wd + (((size_t)cb * 16 + ky * 4 + kx) * CB + ci) * Cout + o0;
-                                for (int o = 0; o < on; ++o) acc[o] = fmaf(a, wrow[o], acc[o]);
+                                for (int o = 0; o < on; ++o) acc[o] = fmaf(a, OPND(wrow[o]), acc[o]);
                             }
                         }
                     }
@@ -666,13 +693,13 @@ GSAO_API int gsao_generator_forward(gsao_ctx* c, void* stream, int32_t n, const 
                         memcpy(xa, c->constant, sizeof(float) * npix * C); /* broadcast const, reference :178 */
                     } else {
                         /* xb holds the affine-applied previous feature */
-                        if (B->is_deconv) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc);
-                        else if (R >= 16) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc);   /* sub-pixel up+conv */
-                        else conv3x3(xb, R / 2, R / 2, Cin, 1, B->w1, C, xc);
+                        if (B->is_deconv) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc, c->bf16);
+                        else if (R >= 16) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc, c->bf16);   /* sub-pixel up+conv */
+                        else conv3x3(xb, R / 2, R / 2, Cin, 1, B->w1, C, xc, c->bf16);
                         blur3x3(xc, R, R, C, B->blur, xa);
                     }
                 } else {
-                    conv3x3(xb, R, R, C, 0, B->w2, C, xa);
+                    conv3x3(xb, R, R, C, 0, B->w2, C, xa, c->bf16);
                 }
                 noise_bias_act(xa, R, R, C, nz, B->nscale[k], B->nbias[k]);
                 plane_stats(xa, R, R, C, I1, I2);
@@ -832,7 +859,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
             const size_t npix = (size_t)R * R;
             nchw_to_nhwc(feats[i] + (size_t)s * npix * d->I, R, R, d->I, fin);
             /* cvt_block: conv3x3+bias -> BN -> LeakyReLU -> Dropout(identity), reference networks_seg.py:64-79 */
-            conv3x3(fin, R, R, d->I, 0, d->cvt_w, d->F, ya);
+            conv3x3(fin, R, R, d->I, 0, d->cvt_w, d->F, ya, c->bf16);
             bias_bn_act(ya, npix, d->F, d->cvt_b, d->cvt_s, d->cvt_rm, d->cvt_beta);
             /* concat(prev, cvt) on channels, reference :108-109 */
             if (i > 0) {
@@ -847,10 +874,10 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                 /* main_block: nearest x2 -> DecoderResBlock, reference :7-46, :86-88 */
                 const int R2 = 2 * R;
                 const size_t np2 = (size_t)R2 * R2;
-                if (R2 >= 16) deconv4x4s2(cat, R, R, d->in_c, d->a_w, d->cs, ya);   /* sub-pixel up+conv */
-                else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya);
+                if (R2 >= 16) deconv4x4s2(cat, R, R, d->in_c, d->a_w, d->cs, ya, c->bf16);   /* sub-pixel up+conv */
+                else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya, c->bf16);
                 bias_bn_act(ya, np2, d->cs, d->a_b, d->a_s, d->a_rm, d->a_beta);
-                conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb);
+                conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb, c->bf16);
                 bias_bn_act(yb, np2, d->cs, d->b_b, d->b_s, d->b_rm, d->b_beta);
 #pragma omp parallel for schedule(static)
                 for (int y = 0; y < R2; ++y)
@@ -862,7 +889,8 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                             float sc;
                             if (d->has_sc) {
                                 float acc = 0.0f;
-                                for (int ch = 0; ch < d->in_c; ++ch) acc = fmaf(src[ch], d->sc_w[(size_t)ch * d->cs + o], acc);
+                                const int bf = c->bf16;
+                                for (int ch = 0; ch < d->in_c; ++ch) acc = fmaf(OPND(src[ch]), OPND(d->sc_w[(size_t)ch * d->cs + o]), acc);
                                 sc = acc + d->sc_b[o];
                             } else {
                                 sc = src[o];
@@ -873,7 +901,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
             } else {
                 /* final conv3x3 + bias -> logits, then argmax (first maximum), reference :91-92, seg_solver.py:326 */
                 const int nc = d->cs;
-                conv3x3(cat, R, R, d->in_c, 0, d->f_w, nc, ya);
+                conv3x3(cat, R, R, d->in_c, 0, d->f_w, nc, ya, 0);   /* final conv: fp32 in both modes */
                 for (size_t p = 0; p < npix; ++p) {
                     int best = 0;
                     float bv = 0.0f;
