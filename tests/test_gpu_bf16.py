@@ -1,0 +1,111 @@
+"""GPU tests of the bf16-MFMA mode (BASELINE.json configs[4]: "bf16 MFMA", fp32 accumulate and statistics).
+
+Tolerance contract (stated here, loosened from the fp32 path's bit equality / 1e-3):
+ * the arithmetic differs from fp32 only in the operands of the MFMA convolutions (inputs after AdaIN and
+   weights rounded to bf16, 8 significant bits) -- every other step is the canonical fp32 code;
+ * against the C oracle run in the same mode (oracle/c/gsa_oracle.c, bf16r()) the first synthesis level must
+   agree to fp32 rounding (<= 2e-6 of the tensor's range): same operands, only the matrix core's internal
+   summation order differs (tools/probe/).  Deeper levels amplify single flipped bf16 roundings, so the
+   end-to-end bars are: max|d rgb| <= 3 % and mean|d rgb| <= 0.3 % of the rgb range, masks agree on >= 99.5 %
+   of the pixels;
+ * against the fp32 path: max <= 6 %, mean <= 0.6 % of the range, masks agree on >= 99 % of the pixels.
+The synthetic weights put rgb in about [-7, 7]; "range" is max|reference|.
+"""
+import numpy as np
+import pytest
+
+from tests.common import gan_setup, reduced_setup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _build(setup, batch, precision):
+    from gan_segmentation_amd.image_generator import ImageGenerator
+    gcfg, gp, dcfg, dp, _z, _noise = setup
+    return ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[0], batch_size=batch, precision=precision)
+
+
+def _rel(a, b):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    scale = float(np.abs(b).max())
+    return d.max() / scale, d.mean() / scale
+
+
+def _check_against(rgb, mask, rgb_ref, mask_ref, max_rel, mean_rel, min_agree, what):
+    mx, mean = _rel(rgb, rgb_ref)
+    agree = float(np.mean(np.asarray(mask) == np.asarray(mask_ref)))
+    assert mx <= max_rel and mean <= mean_rel, "%s: rgb max %.3e mean %.3e of range" % (what, mx, mean)
+    assert agree >= min_agree, "%s: masks agree on %.5f of the pixels" % (what, agree)
+
+
+def _run(gen, z, noise):
+    rgb, feats, img = gen.netG(z, noise=noise, want_image=True)
+    logits, mask = gen._decoder(*feats, want_mask=True)
+    return rgb.cpu().numpy(), [f.cpu().numpy() for f in feats], img.cpu().numpy(), mask.cpu().numpy()
+
+
+def test_bf16_reduced_against_bf16_oracle_and_fp32(torch_cuda, oracle_lib):
+    setup = reduced_setup(7, batch=3)
+    gcfg, gp, dcfg, dp, z, noise = setup
+    rgb, feats, img, mask = _run(_build(setup, 3, "bf16"), z, noise)
+    o = oracle_lib.Oracle(gcfg, gp, dcfg, dp, precision="bf16")
+    rgb_o, _img_o, feats_o = o.generator(z, noise)
+    _logits_o, mask_o = o.decoder(feats_o)
+    mx, _ = _rel(feats[0], feats_o[0])
+    assert mx <= 2e-6, "4x4 level must agree with the bf16 oracle to fp32 rounding, got %.3e" % mx
+    _check_against(rgb, mask, rgb_o, mask_o, 3e-2, 3e-3, 0.995, "bf16 HIP vs bf16 oracle")
+    # the mode really is a different arithmetic, and stays close to the canonical fp32 path
+    rgb32, _f32, img32, mask32 = _run(_build(setup, 3, "fp32"), z, noise)
+    assert not np.array_equal(rgb, rgb32)
+    _check_against(rgb, mask, rgb32, mask32, 6e-2, 6e-3, 0.99, "bf16 HIP vs fp32 HIP")
+    o32 = oracle_lib.Oracle(gcfg, gp, dcfg, dp)
+    assert np.array_equal(o32.generator(z, noise)[0], rgb32), "the fp32 context next to a bf16 one stays bit-exact"
+
+
+def test_bf16_fused_generate_equals_two_calls(torch_cuda):
+    setup = reduced_setup(7, batch=5, trivial_norm=False)
+    _gcfg, _gp, _dcfg, _dp, z, noise = setup
+    gen = _build(setup, 5, "bf16")
+    img, mask = gen.generate_batch(z, noise)
+    _rgb, _feats, img2, mask2 = _run(gen, z, noise)
+    assert np.array_equal(img.cpu().numpy(), img2) and np.array_equal(mask.cpu().numpy(), mask2)
+    # batch composition still does not change a sample (sharding property)
+    img_a, mask_a = gen.generate_batch(z[3:], [a[3:] for a in noise])
+    assert np.array_equal(img_a.cpu().numpy(), img2[3:]) and np.array_equal(mask_a.cpu().numpy(), mask2[3:])
+
+
+def test_precision_is_fixed_once_weights_are_committed(torch_cuda):
+    from gan_segmentation_amd import _lib
+    gen = _build(reduced_setup(7, batch=1), 1, "fp32")
+    ctx = gen.netG._model.ctx
+    with pytest.raises(_lib.GsaError, match="gsa_set_precision must precede"):
+        ctx.set_precision("bf16")
+    ctx.set_precision("fp32")          # re-stating the current mode is fine
+    with pytest.raises(KeyError):
+        ctx.set_precision("fp8")
+    with pytest.raises(_lib.GsaError, match="precision must be one of"):
+        _build(reduced_setup(7, batch=1), 1, "fp16")
+
+
+def test_config5_cars_512_bf16(torch_cuda, oracle_lib):
+    """BASELINE.json configs[4]: stylegan-cars 512^2 synthesis + decoder, bf16 MFMA, 4 samples per GPU."""
+    setup = gan_setup("cars", batch=4)
+    gcfg, gp, dcfg, dp, z, noise = setup
+    gen = _build(setup, 4, "bf16")
+    img, mask = gen.generate_batch(z, noise)
+    rgb, _feats, img2, mask2 = _run(gen, z, noise)
+    assert np.array_equal(img.cpu().numpy(), img2) and np.array_equal(mask.cpu().numpy(), mask2)
+    o = oracle_lib.Oracle(gcfg, gp, dcfg, dp, precision="bf16")
+    rgb_o, img_o, feats_o = o.generator(z[:1], [a[:1] for a in noise])
+    _logits_o, mask_o = o.decoder(feats_o)
+    _check_against(rgb[:1], mask2[:1], rgb_o, mask_o, 3e-2, 3e-3, 0.995, "cars bf16 HIP vs bf16 oracle")
+    assert np.abs(img2[:1].astype(np.int32) - img_o.astype(np.int32)).mean() <= 2.0   # u8 image: mean error <= 2 levels
+    rgb32, _f, _i, mask32 = _run(_build(setup, 4, "fp32"), z, noise)
+    _check_against(rgb, mask2, rgb32, mask32, 6e-2, 6e-3, 0.99, "cars bf16 HIP vs fp32 HIP")
