@@ -412,6 +412,10 @@ struct Launch {
                 const double w = (double)h[15];   // per wave (4 MFMA + 4 memory waves per workgroup)
                 fprintf(stderr, "STAMPWS %-24s %-16s waves %6llu  mfma: work %9.0f barrier %9.0f | mem: write %9.0f load %9.0f epi %9.0f barrier %9.0f\n",
                         kname, label, h[15], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w);
+            } else if (h[15] && h[8]) {           // double-buffered persistent loop: cycles per ITEM per wave
+                const double w = (double)h[12];
+                fprintf(stderr, "STAMPDB %-70s %-14s waves %6llu items/wave %5.1f | per item: write %6.0f load %6.0f (epi-loads %5.0f index %5.0f bulk %5.0f) mfma %6.0f epi %6.0f barrier %6.0f\n",
+                        kname, label, h[15], h[12] / (double)h[15], h[6] / w, h[7] / w, h[0] / w, h[1] / w, h[2] / w, h[8] / w, h[9] / w, h[10] / w);
             } else if (h[15]) {
                 const double w = (double)h[15];
                 fprintf(stderr, "STAMP %-40s %-16s waves %8llu  load %7.0f  write %6.0f  bar %6.0f  blocks %8.0f  epi %7.0f\n", kname,
@@ -425,12 +429,7 @@ struct Launch {
     }
 };
 
-const char* conv_kernel_name(const gsa_ctx* c, int H, int Cout, int n, int epi, bool sc) {
-    static thread_local char buf[112];
-    snprintf(buf, sizeof buf, "void gsa::conv3x3_mfma<%s, %d, %s, %s>(gsa::ConvParams)", conv_geom_name(H, H, Cout, n), epi,
-             sc ? "true" : "false", c->bf16 ? "true" : "false");
-    return buf;
-}
+const char* conv_kernel_name(const ConvParams& cp, int n, int epi, bool sc) { return conv3x3_kernel_name(cp, epi, sc, n); }
 
 }  // namespace
 
@@ -865,7 +864,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                     } else {
                         cp.up = 1;
                         snprintf(layer, sizeof layer, "g.%d.conv_1", R);
-                        Launch lp(c, s, conv_kernel_name(c, R, C, n, EPI_RAW, false), layer, 2.0 * px * C * Cin * 9, 4.0 * (px / 4 * Cin + px * C));
+                        Launch lp(c, s, conv_kernel_name(cp, n, EPI_RAW, false), layer, 2.0 * px * C * Cin * 9, 4.0 * (px / 4 * Cin + px * C));
                         HIP_TRY(launch_conv3x3(cp, EPI_RAW, false, n, s));
                     }
                     pp.src = c->t_raw; pp.src_per_sample = 1; pp.blur = B.blur;
@@ -882,7 +881,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 cp.noise = nz; cp.nscale = B.nscale[1]; cp.nbias = B.nbias[1]; cp.partials = c->partials; cp.acc = c->stat_acc;
                 snprintf(layer, sizeof layer, "g.%d.conv_2", R);
                 const bool ws = conv_uses_ws(cp, EPI_SYNTH, false, n);
-                Launch lp(c, s, ws ? "void gsa::conv3x3_ws<ws, 1>(gsa::ConvParams)" : conv_kernel_name(c, R, C, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
+                Launch lp(c, s, ws ? "void gsa::conv3x3_ws<ws, 1>(gsa::ConvParams)" : conv_kernel_name(cp, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
                 prow = ws ? 0 : conv_stat_rows(R, R, C, n);
             }
@@ -929,7 +928,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             cp.wpk = d.cvt_w; cp.Cout = d.F; cp.out = c->cvt[i];
             cp.bias = d.cvt_b; cp.bn_s = d.cvt_s; cp.bn_rm = d.cvt_rm; cp.bn_beta = d.cvt_beta;
             snprintf(layer, sizeof layer, "d.cvt_%d", i);
-            Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(c, R, d.F, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
+            Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
             HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
         }
         if (!d.is_last) {
@@ -952,7 +951,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                     cp.up = 0;
                     HIP_TRY(launch_subpixel(cp, EPI_DEC, d.has_sc, n, s));
                 } else {
-                    Launch lp(c, s, conv_kernel_name(c, R2, d.cs, n, EPI_DEC, d.has_sc), layer,
+                    Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, d.has_sc), layer,
                               2.0 * px2 * d.cs * d.in_c * (9 + (d.has_sc ? 1 : 0)), 4.0 * (px * d.in_c + px2 * d.cs * (d.has_sc ? 2 : 1)));
                     HIP_TRY(launch_conv3x3(cp, EPI_DEC, d.has_sc, n, s));
                 }
@@ -966,7 +965,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = R2 >= 16 ? 1 : 0; }   // sub-pixel conv a stores the shortcut at input resolution
                 else { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
-                Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(c, R2, d.cs, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
+                Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
             }
         } else {

@@ -177,7 +177,7 @@ struct WorkTile { int n, g, y0, x0, row; };   // row = tile index inside the ima
 // fp32 MFMAs, accumulation / epilogue / statistics stay fp32.  LDS offsets are in 4-byte slots in both modes:
 // a staged pixel is PX slots, a (tap, 16 couts, 16 channels) weight chunk TS slots.
 template <int TH, int TW, int WM, int WN, int NT, int EPI, bool SC, bool BF>
-__global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
     constexpr int NW = WM * WN, NTHR = 64 * NW;
     constexpr int PW = TW / 4, MT = (TH / 4) * PW / WM;
     constexpr int LH = TH + 2, LW = TW + 2;
@@ -213,6 +213,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
     const int w_begin = blockIdx.x * chunk;
     const int w_end = min(p.total_tiles, w_begin + chunk);
     if (w_begin >= w_end) return;
+    // Index arithmetic is kept off the vector ALU: f32 MFMAs and VALU instructions do not co-execute on a SIMD
+    // (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in the PMC passes), so every VALU instruction of one wave is taken from
+    // the MFMA stream of the other.  Only the first tile of a workgroup is decoded with divisions (wave-uniform);
+    // the walk (tx, ty, g, n) is incremental, and everything per thread that does not depend on the tile
+    // (tile-local pixel coordinates, weight offsets) is computed once.
     auto decode = [&](int w) {
         WorkTile t;
         const int tx = w % p.tiles_x;
@@ -225,15 +230,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         t.row = ty * p.tiles_x + tx;
         return t;
     };
+    auto advance = [&](const WorkTile& t) {      // the tile after t in (n, g, ty, tx) order
+        WorkTile u = t;
+        u.x0 += TW; u.row += 1;
+        if (u.x0 == p.W) {
+            u.x0 = 0; u.y0 += TH;
+            if (u.y0 == p.H) {
+                u.y0 = 0; u.row = 0; u.g += 1;
+                if (u.g == p.groups) { u.g = 0; u.n += 1; }
+            }
+        }
+        return u;
+    };
+    int t_ly[AIT], t_lx[AIT], t_lds[AIT];        // tile-local coordinates / LDS offset of the pixels this thread stages
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+        const int idx = tid + it * NTHR;
+        t_ly[it] = idx / LW - 1; t_lx[it] = idx % LW - 1;
+        t_lds[it] = idx < LH * LW ? (idx / LW) * RS + (idx % LW) * PX : -1;
+    }
     auto tile_pixels = [&](const WorkTile& t, TilePixel (&tp)[AIT]) {
 #pragma unroll
         for (int it = 0; it < AIT; ++it) {
-            const int idx = tid + it * NTHR;
-            const int ly = idx / LW, lx = idx % LW;
-            const int gy = t.y0 - 1 + ly, gx = t.x0 - 1 + lx;
-            const bool stage = idx < LH * LW;
-            const bool inside = stage && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            tp[it].lds = stage ? ly * RS + lx * PX : -1;
+            const int gy = t.y0 + t_ly[it], gx = t.x0 + t_lx[it];
+            const int lx = t_lx[it] + 1; (void)lx;
+            const bool inside = t_lds[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            tp[it].lds = t_lds[it];
             tp[it].pix = inside ? (t.n * p.Hs + (gy >> p.up)) * p.Ws + (gx >> p.up) : -1;
 #ifdef GSA_DBG_HOOKS
             if ((p.dbg & 1) && inside) tp[it].pix = lx & 1;      // timing-only: cache-resident input
@@ -266,6 +288,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
     STAMP_DECL;
     STAMP(0);
 
+    int wofs[BIT];                               // this thread's 16-byte pieces of a weight block: q*nblk*SEG + 4r
+#pragma unroll
+    for (int j = 0; j < BIT; ++j) {
+        const int i = min(tid + j * NTHR, NB4 - 1);    // clamped: duplicates rewrite the same value
+        wofs[j] = (i / (SEG / 4)) * nblk * SEG + (i % (SEG / 4)) * 4;
+    }
     // prefetch of one (tile, block) item into registers -- every load unconditional
     auto load_item = [&](const WorkTile& t, int cb, const TilePixel (&tp)[AIT]) {
         const bool first = cb < nblk0;
@@ -274,12 +302,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         const int coff = (first ? cb : cb - nblk0) * 16;
 #pragma unroll
         for (int it = 0; it < AIT; ++it) load_pixel(ra[it], src, Cs, coff, tp[it]);
+        const float* wblk = p.wpk + ((size_t)t.g * Q * nblk + cb) * SEG;      // wave-uniform
 #pragma unroll
-        for (int j = 0; j < BIT; ++j) {
-            const int i = min(tid + j * NTHR, NB4 - 1);    // clamped: duplicates rewrite the same value
-            const int q = i / (SEG / 4), r = i % (SEG / 4);
-            rb[j] = reinterpret_cast<const f32x4*>(p.wpk + ((size_t)(t.g * Q + q) * nblk + cb) * SEG)[r];
-        }
+        for (int j = 0; j < BIT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wblk + wofs[j]);
         if (SC) {
 #pragma unroll
             for (int j = 0; j < SIT; ++j) {
@@ -315,44 +340,53 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         }
     };
 
+    // Epilogue inputs live in registers of their own so that their loads can be ISSUED BEFORE the bulk prefetch
+    // of the item after next: a wave's loads return in order, and behind ~11 bulk loads per lane the few epilogue
+    // loads waited out the whole memory time of that prefetch (in-kernel timers: 6-9k of 17-27k cycles per item).
+    const int prow_in_patch = lane >> 4;
+    const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;   // quad-transposed layout: lane -> (x = lane&3, channels 4*((lane>>2)&3)..+3)
+    float4 nzs[EPI == EPI_SYNTH ? MT : 1];
+    float e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
+    f32x4 rr[EPI == EPI_DEC ? MT : 1][EPI == EPI_DEC ? NT : 1];
+    const bool has_resid = EPI == EPI_DEC && p.resid != nullptr;
+    auto epilogue_loads = [&](const WorkTile& tc) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
+            const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4;
+            if (EPI == EPI_SYNTH) nzs[mt] = *reinterpret_cast<const float4*>(p.noise + (size_t)(tc.n * p.H + y) * p.W + x);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = tc.g * COUT_T + (wn * NT + nt) * 16 + i16;
+            e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = 0.f;
+            if (EPI == EPI_SYNTH) { e0[nt] = p.nscale[co]; e1[nt] = p.nbias[co]; }
+            if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
+            if (SC) scb[nt] = p.sc_bias[co];
+        }
+        if (EPI == EPI_DEC && has_resid) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
+                const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4 + xj;
+                const size_t rp = p.resid_up ? (size_t)(tc.n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1)
+                                             : (size_t)(tc.n * p.H + y) * p.W + x;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    rr[mt][nt] = *reinterpret_cast<const f32x4*>(p.resid + rp * p.Cout + tc.g * COUT_T + (wn * NT + nt) * 16 + cq4);
+            }
+        }
+    };
+
     auto epilogue = [&](const WorkTile& tc) {
-            // ---- epilogue of tile tc.  C layout: lane -> (channel = lane&15, patch row = lane>>4),
-            // reg -> patch column.  Every global load (noise, residual, per-channel constants) is
-            // issued before the first store: a load cannot move above a store that might alias it.
-            const int prow_in_patch = lane >> 4;
+            // ---- epilogue of tile tc (after epilogue_loads(tc)).  C layout: lane -> (channel = lane&15,
+            // patch row = lane>>4), reg -> patch column.
             size_t pixs[MT];
-            float4 nzs[EPI == EPI_SYNTH ? MT : 1];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
                 const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4;
                 pixs[mt] = (size_t)(tc.n * p.H + y) * p.W + x;
-                if (EPI == EPI_SYNTH) nzs[mt] = *reinterpret_cast<const float4*>(p.noise + pixs[mt]);
-            }
-            float e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int co = tc.g * COUT_T + (wn * NT + nt) * 16 + i16;
-                e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = 0.f;
-                if (EPI == EPI_SYNTH) { e0[nt] = p.nscale[co]; e1[nt] = p.nbias[co]; }
-                if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
-                if (SC) scb[nt] = p.sc_bias[co];
-            }
-            // residual and stores use the quad-transposed layout: lane -> (x = lane&3, channels 4*((lane>>2)&3)..+3)
-            const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;
-            f32x4 rr[EPI == EPI_DEC ? MT : 1][EPI == EPI_DEC ? NT : 1];
-            const bool has_resid = EPI == EPI_DEC && p.resid != nullptr;
-            if (EPI == EPI_DEC && has_resid) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
-                    const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4 + xj;
-                    const size_t rp = p.resid_up ? (size_t)(tc.n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1)
-                                                 : pixs[mt] + xj;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        rr[mt][nt] = *reinterpret_cast<const f32x4*>(p.resid + rp * p.Cout + tc.g * COUT_T + (wn * NT + nt) * 16 + cq4);
-                }
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -478,15 +512,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         // items in flight: `tc/cb` is being multiplied out of LDS buffer it&1, `tr/cbr` sits in the
         // prefetch registers (written to buffer (it+1)&1 at the top of the next iteration)
         const int total_items = (w_end - w_begin) * nblk;
-        auto item_at = [&](int i, WorkTile& t, int& cbi) {
-            const int ic = min(i, total_items - 1);
-            t = decode(w_begin + ic / nblk);
-            cbi = ic % nblk;
+        // item i+1 of (t, cbi), or the same item again when i+1 is past the end (a harmless reload)
+        auto next_item = [&](int i, WorkTile& t, int& cbi, TilePixel (&tp)[AIT]) {
+            if (i + 1 >= total_items) return;
+            if (++cbi == nblk) {
+                cbi = 0;
+                t = advance(t);
+                tile_pixels(t, tp);
+            }
         };
         WorkTile tc, tr;
         int cb = 0, cbr = 0;
         TilePixel tpr[AIT];
-        item_at(0, tc, cb);
+        tc = decode(w_begin);
         tile_pixels(tc, tpr);
         load_item(tc, cb, tpr);
         int n_aff = tc.n;
@@ -495,8 +533,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
             __syncthreads();
         }
         write_item(cb, tpr, 0);
-        item_at(1, tr, cbr);
-        tile_pixels(tr, tpr);
+        tr = tc; cbr = cb;
+        next_item(0, tr, cbr, tpr);
         load_item(tr, cbr, tpr);
         if (has_aff && total_items > 1 && tr.n != n_aff) {     // table of item 1's sample (buffer reuse is safe: item 0 is staged)
             __syncthreads();
@@ -504,26 +542,41 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
             n_aff = tr.n;
         }
         __syncthreads();
+        unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, sw = 0, sl = 0, sm = 0, se = 0, sb = 0, ka = 0, kb = 0, s0 = 0, s1 = 0, s2 = 0;
+        (void)ka; (void)kb; (void)s0; (void)s1; (void)s2; (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)k5; (void)sw; (void)sl; (void)sm; (void)se; (void)sb;
         for (int it = 0; it < total_items; ++it) {
             const bool has_next = it + 1 < total_items;
+            TICK(k0);
 #ifdef GSA_DBG_HOOKS
             if (!(p.dbg & 8))        // timing-only: no LDS staging writes in the steady state
 #endif
             if (has_next) write_item(cbr, tpr, (it + 1) & 1);  // item it+1: registers -> the other LDS buffer
-            WorkTile t2; int cb2;
-            item_at(it + 2, t2, cb2);
-            tile_pixels(t2, tpr);
+            TICK(k1);
+            if (cb == nblk - 1) epilogue_loads(tc);            // ahead of the bulk prefetch: loads return in order
+            TICK(ka);
+            WorkTile t2 = tr; int cb2 = cbr;
+            next_item(it + 1, t2, cb2, tpr);
+            TICK(kb);
             load_item(t2, cb2, tpr);                           // item it+2 -> registers, lands during the MFMAs
+            TICK(k2);
+            TSUM(s0, k1, ka); TSUM(s1, ka, kb); TSUM(s2, kb, k2);
             mfma_item(it & 1);
+            TICK(k3);
             if (cb == nblk - 1) epilogue(tc);
+            TICK(k4);
             if (has_aff && it + 2 < total_items && t2.n != n_aff) {   // wave-uniform, rare: next sample's AdaIN table
                 __syncthreads();                                      // item it+1 (old table) is staged by every wave
                 write_aff();
                 n_aff = t2.n;
             }
             __syncthreads();
+            TICK(k5);
+            TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4); TSUM(sb, k4, k5);
             tc = tr; cb = cbr; tr = t2; cbr = cb2;
         }
+        TFLUSH(6, sw); TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(9, se); TFLUSH(10, sb);
+        TFLUSH(0, s0); TFLUSH(1, s1); TFLUSH(2, s2);
+        TFLUSH(12, (unsigned long long)total_items); TFLUSH(15, 1ull);
         return;
     }
 
@@ -554,7 +607,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         if (!has_next) { w2 = w; cb2 = cb; }
         WorkTile tn = tc;
         if (w2 != w) {
-            tn = decode(w2);
+            tn = advance(tc);
             tile_pixels(tn, tpn);
         } else {
 #pragma unroll
@@ -565,7 +618,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma(ConvParams p) {
         mfma_item(0);
         __builtin_amdgcn_sched_barrier(0);
 
-        if (cb == nblk - 1) epilogue(tc);
+        if (cb == nblk - 1) { epilogue_loads(tc); epilogue(tc); }
         if (!has_next) break;
         __syncthreads();              // every wave has finished reading this item's LDS image
         if (has_aff && tn.n != n_aff) {   // wave-uniform: the next item belongs to another sample
@@ -1610,6 +1663,8 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
         if (e != hipSuccess) return e;
         wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
         occ_lds = lds;
+        if (getenv("GSA_VERBOSE"))
+            fprintf(stderr, "gsa: conv3x3_mfma<%d,%d,%d,%d,%d,%d,%d,%d> lds %zu B -> %d workgroups/CU\n", TH, TW, WM, WN, NT, EPI, (int)SC, (int)BF, lds, k);
     }
     ConvParams q = p;
     q.tiles_x = p.W / TW;
@@ -1693,6 +1748,15 @@ hipError_t launch_conv3x3_ws(const ConvParams& p, int epi, int n, hipStream_t s)
     if (nt == 2 && epi == EPI_SYNTH) return launch_conv_ws_t<2, EPI_SYNTH>(p, n, s);
     if (nt == 2 && epi == EPI_DEC) return launch_conv_ws_t<2, EPI_DEC>(p, n, s);
     return hipErrorInvalidValue;
+}
+
+// exact C++ name of the instantiation launch_conv3x3 picks (profile labels spell kernels as rocprofv3 prints them)
+const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
+    static thread_local char buf[128];
+    const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
+    snprintf(buf, sizeof buf, "void gsa::conv3x3_mfma<%d, %d, %d, %d, %d, %d, %s, %s>(gsa::ConvParams)", c.th, c.th, c.wm, c.wn, c.nt,
+             epi, sc ? "true" : "false", p.bf16 ? "true" : "false");
+    return buf;
 }
 
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
