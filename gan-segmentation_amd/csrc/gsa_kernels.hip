@@ -54,7 +54,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define STAMP_FLUSH(nph) do {} while (0)
 #endif
 
-__device__ __forceinline__ float lrelu(float v) { return v > 0.0f ? v : 0.2f * v; }
+// LeakyReLU(0.2): max(v, 0.2*v) is the same value bit for bit as (v > 0 ? v : 0.2*v) -- v > 0 gives v > 0.2v,
+// v < 0 gives 0.2v > v, +-0 and NaN map to themselves -- and is one VALU instruction shorter
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }
 
 // rint(v * scale) as a wrapping 64-bit integer (1.5*2^52 magic constant); order-independent sums
 __device__ __forceinline__ unsigned long long to_fixed(float v, double scale) {
@@ -128,9 +130,11 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
-template <bool HAS_AFF, bool BF = false>
+// MASK = false: the caller knows every staged pixel of the tile lies inside the image (interior tile), so the
+// 16 zero-padding selects per pixel are not emitted.
+template <bool HAS_AFF, bool BF = false, bool MASK = true>
 __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const float4* saff, const TilePixel& tp) {
-    const bool inside = tp.pix >= 0;
+    const bool inside = !MASK || tp.pix >= 0;
     float f[16] = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3],
                    v[2][0], v[2][1], v[2][2], v[2][3], v[3][0], v[3][1], v[3][2], v[3][3]};
 #pragma unroll
@@ -323,14 +327,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < FIT; ++j) sAff[min(tid + j * NTHR, p.C0 - 1)] = rf[j];
     };
-    auto write_item = [&](int cb, const TilePixel (&tp)[AIT], int buf = 0) {
+    auto is_edge = [&](const WorkTile& t) { return t.y0 == 0 || t.x0 == 0 || t.y0 + TH == p.H || t.x0 + TW == p.W; };
+    auto write_item = [&](int cb, const TilePixel (&tp)[AIT], bool edge, int buf = 0) {
         float* a_img = sA + buf * (LH * RS);
-        if (cb < nblk0 && has_aff) {      // wave-uniform
+        const float4* tab = reinterpret_cast<const float4*>(sAff) + cb * 16;
+        if (cb < nblk0 && has_aff) {      // wave-uniform branches
+            if (edge) {
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<true, BF>(a_img, ra[it], reinterpret_cast<const float4*>(sAff) + cb * 16, tp[it]);
+                for (int it = 0; it < AIT; ++it) store_pixel<true, BF, true>(a_img, ra[it], tab, tp[it]);
+            } else {
+#pragma unroll
+                for (int it = 0; it < AIT; ++it) store_pixel<true, BF, false>(a_img, ra[it], tab, tp[it]);
+            }
+        } else if (edge) {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) store_pixel<false, BF, true>(a_img, ra[it], tab, tp[it]);
         } else {
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<false, BF>(a_img, ra[it], reinterpret_cast<const float4*>(sAff), tp[it]);
+            for (int it = 0; it < AIT; ++it) store_pixel<false, BF, false>(a_img, ra[it], tab, tp[it]);
         }
 #pragma unroll
         for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * (Q * SEG))[min(tid + j * NTHR, NB4 - 1)] = rb[j];
@@ -369,8 +383,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
             for (int mt = 0; mt < MT; ++mt) {
                 const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
                 const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4 + xj;
-                const size_t rp = p.resid_up ? (size_t)(tc.n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1)
-                                             : (size_t)(tc.n * p.H + y) * p.W + x;
+                const int ru = p.resid_up;      // 1: the residual lives at half resolution (branch-free addressing)
+                const size_t rp = (size_t)(tc.n * (p.H >> ru) + (y >> ru)) * (p.W >> ru) + (x >> ru);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     rr[mt][nt] = *reinterpret_cast<const f32x4*>(p.resid + rp * p.Cout + tc.g * COUT_T + (wn * NT + nt) * 16 + cq4);
@@ -532,7 +546,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
             write_aff();
             __syncthreads();
         }
-        write_item(cb, tpr, 0);
+        write_item(cb, tpr, is_edge(tc), 0);
         tr = tc; cbr = cb;
         next_item(0, tr, cbr, tpr);
         load_item(tr, cbr, tpr);
@@ -550,7 +564,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #ifdef GSA_DBG_HOOKS
             if (!(p.dbg & 8))        // timing-only: no LDS staging writes in the steady state
 #endif
-            if (has_next) write_item(cbr, tpr, (it + 1) & 1);  // item it+1: registers -> the other LDS buffer
+            if (has_next) write_item(cbr, tpr, is_edge(tr), (it + 1) & 1);  // item it+1: registers -> the other LDS buffer
             TICK(k1);
             if (cb == nblk - 1) epilogue_loads(tc);            // ahead of the bulk prefetch: loads return in order
             TICK(ka);
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     STAMP(1);                                      // [0,1): prologue + first global loads landed
-    write_item(0, tp);
+    write_item(0, tp, is_edge(tc));
     STAMP(2);                                      // [1,2): first LDS write
     __syncthreads();
     STAMP(3);                                      // [2,3): barrier
@@ -629,7 +643,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #ifdef GSA_DBG_HOOKS
         if (!(p.dbg & 8))
 #endif
-        write_item(cb2, tpn);
+        write_item(cb2, tpn, is_edge(tn));
         __syncthreads();
         tc = tn; w = w2; cb = cb2;
 #pragma unroll
