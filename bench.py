@@ -140,13 +140,20 @@ def main():
     noise = [torch.from_numpy(a).to(dev) for a in noise]
     ctx = gen.netG._model.ctx
 
+    # the pairs of every rank land on rank 0 through ONE gather per batch, double buffered so that the transfer
+    # of batch k overlaps the kernels of batch k+1 (dist.PairGatherer); at N=1 the outputs simply stay in HBM
+    gat = gdist.PairGatherer(B, 2 ** mr, gcfg["channels"], device=dev, dst=0, depth=2)
+    state = {"k": 0}
+
     def step():
-        img, mask = gen.generate_batch(z, noise)
-        if world > 1:
-            img, mask = gdist.gather_pairs(img, mask)
-        return img, mask
+        slot = state["k"] & 1
+        state["k"] += 1
+        gat.wait(slot)                       # the gather that last read this buffer (two batches ago)
+        gen.generate_batch(z, noise, out=gat.buffers(slot))
+        gat.submit(slot)
 
     def fence():
+        gat.wait_all()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

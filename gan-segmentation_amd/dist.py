@@ -72,3 +72,59 @@ def gather_pairs(img, mask, counts=None, dst=0, group=None):
         return None, None
     parts = [unpack_pairs(o[:c], R, ch) for o, c in zip(out, counts)]
     return torch.cat([p[0] for p in parts], dim=0), torch.cat([p[1] for p in parts], dim=0)
+
+
+class PairGatherer:
+    """Overlapped, copy-free form of ``gather_pairs`` for a steady stream of equal batches.
+
+    Each rank owns ``depth`` fused send buffers ``[n*R*R*ch image bytes | n*R*R mask bytes]``; the generate
+    kernels write straight into the two views ``buffers(slot)`` returns, so nothing is packed.  ``submit(slot)``
+    starts ONE asynchronous gather of that buffer (RCCL runs it on its own stream once the producing kernels
+    are done) into row ``rank`` of a preallocated ``(world, bytes)`` tensor per slot on ``dst``; the caller
+    goes on to enqueue the next batch and only ``wait(slot)``s before that slot is produced into again, so the
+    transfer over xGMI hides behind the next batch's kernels.  ``result(slot)`` on ``dst`` = per-rank views
+    ``[(img (n,R,R,ch), mask (n,R,R))]`` in rank order (global sample order), no copy."""
+
+    def __init__(self, n, R, channels=3, device="cpu", dst=0, depth=2, group=None):
+        self.n, self.R, self.ch, self.dst, self.depth, self.group = n, R, channels, dst, depth, group
+        self.active = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.img_bytes = n * R * R * channels
+        self.bytes = self.img_bytes + n * R * R
+        self.send = [torch.empty(self.bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.recv = [torch.empty((self.world, self.bytes), dtype=torch.uint8, device=device)
+                     if (self.active and self.rank == dst) else None for _ in range(depth)]
+        self.work = [None] * depth
+
+    def _views(self, flat):
+        return (flat[:self.img_bytes].view(self.n, self.R, self.R, self.ch),
+                flat[self.img_bytes:].view(self.n, self.R, self.R))
+
+    def buffers(self, slot):
+        """(img, mask) views of send buffer ``slot`` -- hand them to ``generate_batch(out=...)``."""
+        return self._views(self.send[slot])
+
+    def submit(self, slot):
+        if not self.active:
+            return
+        out = [self.recv[slot][r] for r in range(self.world)] if self.rank == self.dst else None
+        self.work[slot] = dist.gather(self.send[slot], out, dst=self.dst, group=self.group, async_op=True)
+
+    def wait(self, slot):
+        """The gather last submitted from ``slot`` has completed (stream-ordered on CUDA/HIP tensors)."""
+        w = self.work[slot]
+        if w is not None:
+            w.wait()
+            self.work[slot] = None
+
+    def wait_all(self):
+        for slot in range(self.depth):
+            self.wait(slot)
+
+    def result(self, slot):
+        if not self.active:
+            return [self._views(self.send[slot])]
+        if self.rank != self.dst:
+            return None
+        return [self._views(self.recv[slot][r]) for r in range(self.world)]

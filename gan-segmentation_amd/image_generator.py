@@ -128,9 +128,11 @@ class ImageGenerator:
                     yield img, fs
 
     # -- fused hot path ---------------------------------------------------------------------
-    def generate_batch(self, z, noise=None):
+    def generate_batch(self, z, noise=None, out=None):
         """latents (N,512) [+ noise planes] -> (img (N,R,R,3) u8, mask (N,R,R) u8) on the GPU.
-        The per-batch body of ``main.py generate`` (reference main.py:97-99) in one call."""
+        The per-batch body of ``main.py generate`` (reference main.py:97-99) in one call.
+        ``out=(img, mask)``: write into these contiguous uint8 device tensors instead of new ones
+        (e.g. the fused send buffer of ``dist.PairGatherer``)."""
         if self._decoder is None:
             raise RuntimeError("attach_decoder() first")
         g = self.netG
@@ -138,8 +140,14 @@ class ImageGenerator:
         model = g._model
         dev = model.device
         R = 2 ** self.max_res_log2
-        img = torch.empty((n, R, R, g.nc), device=dev, dtype=torch.uint8)
-        mask = torch.empty((n, R, R), device=dev, dtype=torch.uint8)
+        if out is None:
+            img = torch.empty((n, R, R, g.nc), device=dev, dtype=torch.uint8)
+            mask = torch.empty((n, R, R), device=dev, dtype=torch.uint8)
+        else:
+            img, mask = out
+            for t, shape in ((img, (n, R, R, g.nc)), (mask, (n, R, R))):
+                if tuple(t.shape) != shape or t.dtype != torch.uint8 or t.device != dev or not t.is_contiguous():
+                    raise ValueError("out tensors must be contiguous uint8 %s on %s" % (shape, dev))
         model.ctx.generate(current_stream_ptr(dev), n, z.data_ptr(), [a.data_ptr() for a in noise],
                            img.data_ptr(), mask.data_ptr())
         return img, mask

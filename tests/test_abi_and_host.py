@@ -110,6 +110,33 @@ if rank == 0:
     print("GATHER_OK")
 else:
     assert gi is None
+# the overlapped, copy-free gatherer of bench.py: 3 batches of 2 samples per rank through 2 slots
+z6, noise6 = W.synthetic_inputs(gcfg, 12, seed_z=7, seed_noise=8)
+R = 2 ** 5
+gat = gdist.PairGatherer(2, R, 3, device="cpu", dst=0, depth=2)
+seen = []
+for k in range(3):
+    slot = k & 1
+    gat.wait(slot)
+    lo = (k * world + rank) * 2
+    bi, bm = o.generate(z6[lo:lo + 2], [a[lo:lo + 2] for a in noise6])
+    img_v, mask_v = gat.buffers(slot)
+    img_v.copy_(torch.from_numpy(bi)); mask_v.copy_(torch.from_numpy(bm))
+    gat.submit(slot)
+    gat.wait(slot)                                # CPU tensors: read back right away
+    if rank == 0:
+        parts = gat.result(slot)
+        assert len(parts) == world
+        seen.append((torch.cat([p[0] for p in parts]).numpy().copy(), torch.cat([p[1] for p in parts]).numpy().copy()))
+    else:
+        assert gat.result(slot) is None
+gat.wait_all()
+if rank == 0:
+    for k, (gi2, gm2) in enumerate(seen):
+        lo = k * world * 2
+        fi, fm = o.generate(z6[lo:lo + 4], [a[lo:lo + 4] for a in noise6])
+        assert np.array_equal(gi2, fi) and np.array_equal(gm2, fm)
+    print("GATHERER_OK")
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -125,7 +152,7 @@ def test_world_size_2_gather_on_gloo(tmp_path, oracle_lib):
          "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
         capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "GATHER_OK" in out.stdout
+    assert "GATHER_OK" in out.stdout and "GATHERER_OK" in out.stdout
 
 
 def test_dataset_writer_files_and_throughput(tmp_path):
