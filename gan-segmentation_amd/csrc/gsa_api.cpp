@@ -904,7 +904,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
     if (rgb || img) {
         const int l = nlev - 1, R = c->blk[l].R, C = c->blk[l].C, nc = c->gc.channels;
         const double px = N * R * R;
-        Launch lp(c, s, "torgb_kernel", "g.torgb", 2.0 * px * C * nc, px * (4.0 * C + (rgb ? 4.0 * nc : 0) + (img ? nc : 0)));
+        Launch lp(c, s, C <= 16 ? "torgb_direct_kernel" : "torgb_kernel", "g.torgb", 2.0 * px * C * nc, px * (4.0 * C + (rgb ? 4.0 * nc : 0) + (img ? nc : 0)));
         HIP_TRY(launch_torgb(c->x2[l], c->aff2[l], c->rgb_w, c->rgb_b, rgb, img, n, R, R, C, nc, s));
     }
     return GSA_OK;
