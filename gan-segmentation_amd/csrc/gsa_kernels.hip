@@ -68,7 +68,7 @@ __device__ __forceinline__ unsigned long long to_fixed(float v, double scale) {
 // value of another lane of the same aligned quad (DPP quad_perm, no LDS traffic)
 template <int CTRL>
 __device__ __forceinline__ float dpp_quad(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));   // quad_perm: every lane has a source
 }
 
 // 4x4 transpose across the four lanes of an aligned quad (two DPP butterfly steps, no LDS): lane j
@@ -363,12 +363,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
     float e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
     f32x4 rr[EPI == EPI_DEC ? MT : 1][EPI == EPI_DEC ? NT : 1];
     const bool has_resid = EPI == EPI_DEC && p.resid != nullptr;
+    // addresses = wave-uniform base of the patch (scalar ALU) + a per-lane 32-bit offset that never changes
+    const int ru = p.resid_up;      // 1: the residual lives at half resolution
+    const unsigned lane_out = (unsigned)((prow_in_patch * p.W + xj) * p.Cout + cq4);
+    const unsigned lane_res = (unsigned)(((prow_in_patch >> ru) * (p.W >> ru) + (xj >> ru)) * p.Cout + cq4);
+    const unsigned lane_nz = (unsigned)(prow_in_patch * p.W);
     auto epilogue_loads = [&](const WorkTile& tc) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
-            const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4;
-            if (EPI == EPI_SYNTH) nzs[mt] = *reinterpret_cast<const float4*>(p.noise + (size_t)(tc.n * p.H + y) * p.W + x);
+            if (EPI == EPI_SYNTH)
+                nzs[mt] = *reinterpret_cast<const float4*>(p.noise + ((size_t)(tc.n * p.H + tc.y0 + pr * 4) * p.W + tc.x0 + pc * 4) + lane_nz);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -382,12 +387,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
-                const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4 + xj;
-                const int ru = p.resid_up;      // 1: the residual lives at half resolution (branch-free addressing)
-                const size_t rp = (size_t)(tc.n * (p.H >> ru) + (y >> ru)) * (p.W >> ru) + (x >> ru);
+                const float* rbase = p.resid + ((size_t)(tc.n * (p.H >> ru) + ((tc.y0 + pr * 4) >> ru)) * (p.W >> ru) + ((tc.x0 + pc * 4) >> ru)) * p.Cout
+                                     + tc.g * COUT_T + wn * NT * 16;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    rr[mt][nt] = *reinterpret_cast<const f32x4*>(p.resid + rp * p.Cout + tc.g * COUT_T + (wn * NT + nt) * 16 + cq4);
+                    rr[mt][nt] = *reinterpret_cast<const f32x4*>(rbase + nt * 16 + lane_res);
             }
         }
     };
@@ -395,20 +399,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
     auto epilogue = [&](const WorkTile& tc) {
             // ---- epilogue of tile tc (after epilogue_loads(tc)).  C layout: lane -> (channel = lane&15,
             // patch row = lane>>4), reg -> patch column.
-            size_t pixs[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
-                const int y = tc.y0 + pr * 4 + prow_in_patch, x = tc.x0 + pc * 4;
-                pixs[mt] = (size_t)(tc.n * p.H + y) * p.W + x;
-            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = tc.g * COUT_T + (wn * NT + nt) * 16 + i16;
                 unsigned long long I1 = 0, I2 = 0;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const size_t pix = pixs[mt];
+                    const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
+                    const size_t ubase = ((size_t)(tc.n * p.H + tc.y0 + pr * 4) * p.W + tc.x0 + pc * 4) * p.Cout + tc.g * COUT_T + (wn * NT + nt) * 16;
                     float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
                     if (EPI == EPI_SYNTH) {
                         const float nzv[4] = {nzs[mt].x, nzs[mt].y, nzs[mt].z, nzs[mt].w};
@@ -429,7 +427,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
                             v[r] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
                         }
                     }
-                    const size_t ot = (pix + xj) * p.Cout + tc.g * COUT_T + (wn * NT + nt) * 16 + cq4;
                     f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
                     if (EPI == EPI_DEC && has_resid) {
 #pragma unroll
@@ -438,9 +435,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #ifdef GSA_DBG_HOOKS
                     if (!(p.dbg & 4))      // timing-only: no epilogue stores
 #endif
-                    *reinterpret_cast<f32x4*>(p.out + ot) = vt;
+                    *reinterpret_cast<f32x4*>(p.out + ubase + lane_out) = vt;
                     if (SC) {
-                        *reinterpret_cast<f32x4*>(p.out_sc + ot) =
+                        *reinterpret_cast<f32x4*>(p.out_sc + ubase + lane_out) =
                             quad_transpose(accs[mt][nt][0] + scb[nt], accs[mt][nt][1] + scb[nt], accs[mt][nt][2] + scb[nt],
                                            accs[mt][nt][3] + scb[nt], xj);
                     }
