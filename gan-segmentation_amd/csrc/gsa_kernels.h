@@ -38,6 +38,7 @@ struct ConvParams {
     // fused 1x1 shortcut of DecoderResBlock (second output)
     const float* wsc; const float* sc_bias; float* out_sc;
     int tiles_x, tiles_y, groups, total_tiles;   // filled by the launcher
+    int w_resident;                              // filled by the launcher: whole weight panel LDS-resident (conv3x3 DB form)
     unsigned long long* stamps;   // diagnostic build (-DGSA_STAMP) only: per-phase cycle sums
     int dbg;                      // diagnostic build only: bit0 = stage pixel 0 everywhere (timing of a cache-resident input)
     int bf16;                     // 1: bf16 MFMA mode -- wpk/wsc hold bf16 packs [..][tap][kq][16][4], operands rounded at staging

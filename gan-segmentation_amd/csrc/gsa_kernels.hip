@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                            // [NBUF][LH*RS]
     float* sB = sA + NBUF * LH * RS;             // [NBUF][q][tap][ci][16][cg]
-    float* sS = sB + NBUF * Q * SEG;             // SC: [q][ci][16][cg]
+    float* sS = sB + ((DB && p.w_resident) ? ((p.C0 + p.C1) >> 4) : NBUF) * Q * SEG;   // SC: [q][ci][16][cg]; resident weights: all blocks
     f32x4* sAff = reinterpret_cast<f32x4*>(sS + (SC ? Q * TS : 0));   // [C0] (mean, A, B, -)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -288,6 +288,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 
     const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4;
     const bool has_aff = p.aff0 != nullptr;
+    // Resident weights (launcher: one channel group, all nblk blocks fit): the workgroup copies the whole weight
+    // panel into LDS once and the items stage activations only -- for the 16- and 32-channel layers at 512^2 and
+    // 1024^2 the 9-18 KB weight block was a third to a half of every item's staging traffic and instructions.
+    const bool wres = DB && p.w_resident;
     f32x4 ra[AIT][4], rb[BIT], rs[SC ? SIT : 1], rf[FIT];
     STAMP_DECL;
     STAMP(0);
@@ -306,9 +310,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
         const int coff = (first ? cb : cb - nblk0) * 16;
 #pragma unroll
         for (int it = 0; it < AIT; ++it) load_pixel(ra[it], src, Cs, coff, tp[it]);
-        const float* wblk = p.wpk + ((size_t)t.g * Q * nblk + cb) * SEG;      // wave-uniform
+        if (!wres) {
+            const float* wblk = p.wpk + ((size_t)t.g * Q * nblk + cb) * SEG;      // wave-uniform
 #pragma unroll
-        for (int j = 0; j < BIT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wblk + wofs[j]);
+            for (int j = 0; j < BIT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wblk + wofs[j]);
+        }
         if (SC) {
 #pragma unroll
             for (int j = 0; j < SIT; ++j) {
@@ -317,11 +323,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
                 rs[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)(t.g * Q + q) * nblk + cb) * TS)[r];
             }
         }
-        if (has_aff) {     // AdaIN table of the item's sample (copied to LDS when the sample changes)
+        if (DB) {          // the 16 AdaIN entries of this item's channel block travel with the item (lanes 0-15 matter)
+            if (has_aff && cb < nblk0) rf[0] = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0 + cb * 16)[tid & 15];
+        } else if (has_aff) {     // whole AdaIN table of the item's sample (copied to LDS when the sample changes)
 #pragma unroll
             for (int j = 0; j < FIT; ++j)
                 rf[j] = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0)[min(tid + j * NTHR, p.C0 - 1)];
         }
+    };
+    auto write_aff_item = [&](int slot) {     // DB form: sAff = [2][16] entries
+        if (has_aff && tid < 16) sAff[slot * 16 + tid] = rf[0];
     };
     auto write_aff = [&]() {
 #pragma unroll
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
     auto is_edge = [&](const WorkTile& t) { return t.y0 == 0 || t.x0 == 0 || t.y0 + TH == p.H || t.x0 + TW == p.W; };
     auto write_item = [&](int cb, const TilePixel (&tp)[AIT], bool edge, int buf = 0) {
         float* a_img = sA + buf * (LH * RS);
-        const float4* tab = reinterpret_cast<const float4*>(sAff) + cb * 16;
+        const float4* tab = reinterpret_cast<const float4*>(sAff) + (DB ? buf : cb) * 16;
         if (cb < nblk0 && has_aff) {      // wave-uniform branches
             if (edge) {
 #pragma unroll
@@ -346,8 +357,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #pragma unroll
             for (int it = 0; it < AIT; ++it) store_pixel<false, BF, false>(a_img, ra[it], tab, tp[it]);
         }
+        if (!wres) {
 #pragma unroll
-        for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * (Q * SEG))[min(tid + j * NTHR, NB4 - 1)] = rb[j];
+            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * (Q * SEG))[min(tid + j * NTHR, NB4 - 1)] = rb[j];
+        }
         if (SC) {
 #pragma unroll
             for (int j = 0; j < SIT; ++j) reinterpret_cast<f32x4*>(sS)[min(tid + j * NTHR, Q * TS / 4 - 1)] = rs[j];
@@ -455,12 +468,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
             }
             };
 
-    auto mfma_item = [&](int buf) {
+    auto mfma_item = [&](int buf, int cb_res = 0) {
 #ifdef GSA_DBG_HOOKS
         if (p.dbg & 16) return;      // timing-only: no MFMA phase
 #endif
         const float* a_img = sA + buf * (LH * RS);
-        const float* b_img = sB + buf * (Q * SEG);
+        const float* b_img = sB + (wres ? cb_res : buf) * (Q * SEG);
         if constexpr (BF) {
             // ---- bf16: one 16x16x16 MFMA per (tap, patch, cout group); k slot kq = channels 4kq..4kq+3
 #pragma unroll
@@ -537,21 +550,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
         TilePixel tpr[AIT];
         tc = decode(w_begin);
         tile_pixels(tc, tpr);
+        if (wres) {                       // the whole weight panel of the (single) channel group -> LDS, once
+            for (int cbk = 0; cbk < nblk; ++cbk) {
+                const float* wblk = p.wpk + (size_t)cbk * SEG;
+#pragma unroll
+                for (int j = 0; j < BIT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wblk + wofs[j]);
+#pragma unroll
+                for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + cbk * (Q * SEG))[min(tid + j * NTHR, NB4 - 1)] = rb[j];
+            }
+        }
         load_item(tc, cb, tpr);
-        int n_aff = tc.n;
         if (has_aff) {
-            write_aff();
+            write_aff_item(0);
             __syncthreads();
         }
         write_item(cb, tpr, is_edge(tc), 0);
         tr = tc; cbr = cb;
         next_item(0, tr, cbr, tpr);
         load_item(tr, cbr, tpr);
-        if (has_aff && total_items > 1 && tr.n != n_aff) {     // table of item 1's sample (buffer reuse is safe: item 0 is staged)
-            __syncthreads();
-            write_aff();
-            n_aff = tr.n;
-        }
+        write_aff_item(1);                 // entries of item 1 -> slot 1 (read after the barrier below)
         __syncthreads();
         unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, sw = 0, sl = 0, sm = 0, se = 0, sb = 0, ka = 0, kb = 0, s0 = 0, s1 = 0, s2 = 0;
         (void)ka; (void)kb; (void)s0; (void)s1; (void)s2; (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)k5; (void)sw; (void)sl; (void)sm; (void)se; (void)sb;
@@ -571,15 +588,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
             load_item(t2, cb2, tpr);                           // item it+2 -> registers, lands during the MFMAs
             TICK(k2);
             TSUM(s0, k1, ka); TSUM(s1, ka, kb); TSUM(s2, kb, k2);
-            mfma_item(it & 1);
+            mfma_item(it & 1, cb);
             TICK(k3);
             if (cb == nblk - 1) epilogue(tc);
             TICK(k4);
-            if (has_aff && it + 2 < total_items && t2.n != n_aff) {   // wave-uniform, rare: next sample's AdaIN table
-                __syncthreads();                                      // item it+1 (old table) is staged by every wave
-                write_aff();
-                n_aff = t2.n;
-            }
+            write_aff_item(it & 1);        // entries of item it+2 (loaded above) -> the slot item it used; read after the barrier
             __syncthreads();
             TICK(k5);
             TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4); TSUM(sb, k4, k5);
@@ -1706,9 +1719,15 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int Q = NT * WN, COUT_T = 16 * Q;
     constexpr int TS = BF ? 128 : 256;
     constexpr int RS = (TW + 2) * (BF ? 8 : 16) + (BF ? 4 : 8);
-    if (p.C0 > 512 && p.aff0) return hipErrorInvalidValue;   // AdaIN table registers sized for <= 512 channels
     constexpr int NBUF = (Q <= 2 && !SC && TH == 16) ? 2 : 1;   // must match the kernel's DB
-    const size_t lds = sizeof(float) * (NBUF * ((TH + 2) * RS + Q * 9 * TS) + (SC ? Q * TS : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
+    // resident weights: one channel group and a whole panel of at most 40 KB (see the kernel)
+    const int nblk_all = (p.C0 + p.C1) / 16;
+    const bool wres = NBUF == 2 && p.Cout == COUT_T && (size_t)nblk_all * Q * 9 * TS * sizeof(float) <= 40 * 1024 &&
+                      !(getenv("GSA_WRES") && atoi(getenv("GSA_WRES")) == 0);
+    if (NBUF == 1 && p.C0 > 512 && p.aff0) return hipErrorInvalidValue;   // AdaIN table registers sized for <= 512 channels
+    const int wslots = wres ? nblk_all * Q * 9 * TS : NBUF * Q * 9 * TS;
+    const size_t lds = sizeof(float) * (NBUF * (TH + 2) * RS + wslots + (SC ? Q * TS : 0)) +
+                       (p.aff0 ? sizeof(float4) * (NBUF == 2 ? 32 : p.C0) : 0);   // double-buffered form: 2 x 16 AdaIN entries
     auto kern = conv3x3_mfma<TH, TW, WM, WN, NT, EPI, SC, BF>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1716,20 +1735,27 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    static int wgs_per_cu = 0, num_cus = 0;
-    static size_t occ_lds = ~(size_t)0;
-    if (occ_lds != lds) {     // resident workgroups per CU for this LDS footprint
+    // resident workgroups per CU for this LDS footprint (a few distinct footprints per instantiation: cached)
+    static int num_cus = 0;
+    static size_t occ_lds[8];
+    static int occ_k[8], occ_n = 0;
+    int wgs_per_cu = 0;
+    for (int i = 0; i < occ_n; ++i)
+        if (occ_lds[i] == lds) wgs_per_cu = occ_k[i];
+    if (!wgs_per_cu) {
         int dev = 0, k = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, reinterpret_cast<const void*>(kern), 64 * WM * WN, lds);
         if (e != hipSuccess) return e;
         wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
-        occ_lds = lds;
+        if (occ_n < 8) { occ_lds[occ_n] = lds; occ_k[occ_n] = wgs_per_cu; ++occ_n; }
         if (getenv("GSA_VERBOSE"))
-            fprintf(stderr, "gsa: conv3x3_mfma<%d,%d,%d,%d,%d,%d,%d,%d> lds %zu B -> %d workgroups/CU\n", TH, TW, WM, WN, NT, EPI, (int)SC, (int)BF, lds, k);
+            fprintf(stderr, "gsa: conv3x3_mfma<%d,%d,%d,%d,%d,%d,%d,%d> lds %zu B%s -> %d workgroups/CU\n", TH, TW, WM, WN, NT, EPI, (int)SC,
+                    (int)BF, lds, wres ? " (resident weights)" : "", k);
     }
     ConvParams q = p;
+    q.w_resident = wres ? 1 : 0;
     q.tiles_x = p.W / TW;
     q.tiles_y = p.H / TH;
     q.groups = p.Cout / COUT_T;
