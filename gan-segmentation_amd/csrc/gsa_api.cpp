@@ -857,8 +857,8 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                     if (B.is_deconv || R >= 16) {
                         // Deconvolution 4x4 s2, or nearest-x2 + conv3x3 in sub-pixel form (same kernel)
                         snprintf(layer, sizeof layer, B.is_deconv ? "g.%d.deconv_1" : "g.%d.conv_1", R);
-                        static thread_local char kn[96];
-                        snprintf(kn, sizeof kn, "void gsa::subpixel_mfma<%s, 0, false, %s>(gsa::ConvParams)", subpixel_geom_name(R, R, C, n), c->bf16 ? "true" : "false");
+                        static thread_local char kn[128];
+                        snprintf(kn, sizeof kn, "%s", subpixel_kernel_name(cp, EPI_RAW, false, n));
                         Launch lp(c, s, kn, layer, 2.0 * px * C * Cin * 4, 4.0 * (px / 4 * Cin + px * C));
                         HIP_TRY(launch_subpixel(cp, EPI_RAW, false, n, s));
                     } else {
@@ -944,8 +944,8 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 if (d.has_sc) { cp.wsc = d.sc_w; cp.sc_bias = d.sc_b; cp.out_sc = c->scb[i]; }
                 snprintf(layer, sizeof layer, "d.main_%d.a", i);
                 if (R2 >= 16) {   // sub-pixel form: 4 taps per output instead of 9
-                    static thread_local char kn[96];
-                    snprintf(kn, sizeof kn, "void gsa::subpixel_mfma<%s, 2, %s, %s>(gsa::ConvParams)", subpixel_geom_name(R2, R2, d.cs, n), d.has_sc ? "true" : "false", c->bf16 ? "true" : "false");
+                    static thread_local char kn[128];
+                    snprintf(kn, sizeof kn, "%s", subpixel_kernel_name(cp, EPI_DEC, d.has_sc, n));
                     Launch lp(c, s, kn, layer, 2.0 * px2 * d.cs * d.in_c * 4 + (d.has_sc ? 2.0 * px * d.cs * d.in_c : 0.0),
                               4.0 * (px * d.in_c + px2 * d.cs + (d.has_sc ? px * d.cs : 0.0)));
                     cp.up = 0;

@@ -1221,6 +1221,255 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// subpixel_mfma for layers with ONE output-channel group whose whole weight panel fits in LDS (the 512^2 ->
+// 1024^2 layers: 16 output channels, 32-64 input channels).  There the 16 KB weight block was 2.5x the 6.4 KB
+// activation block of every (tile, channel-block) item, re-read from L2 by each of 32768 tiles.  Here the
+// workgroups are persistent: the panel is copied to LDS once, a workgroup walks a contiguous range of tiles,
+// the activation image is double buffered (one barrier per item) and the loads of item i+2 fly during the
+// MFMAs of item i -- the structure of conv3x3_mfma's double-buffered form.  Arithmetic order per output is
+// unchanged (bit-identical results).
+template <int NT, int EPI, bool SC, bool BF>
+__global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
+    constexpr int PX = BF ? 8 : 16, TS = BF ? 128 : 256, KQ = BF ? 2 : 4;
+    constexpr int LH = 10, LW = 10, RS = LW * PX + (BF ? 4 : 8);
+    constexpr int SEG = 16 * TS, NB4 = NT * SEG / 4, BIT = (NB4 + 511) / 512;
+    constexpr int SIT = (NT * TS / 4 + 511) / 512;
+    const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // The workgroup is two halves of 4 waves (one CU holds one workgroup, every SIMD one wave of each half): each
+    // half walks its own tiles through its own double-buffered activation image, both read the ONE weight panel.
+    const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    float* sW = smem;                              // [nblk][q][tap16][ci][16][cg]
+    float* sS = sW + nblk * NT * SEG;              // SC: [nblk][q][ci][16][cg]
+    float* sA = sS + (SC ? nblk * NT * TS : 0) + half * (2 * LH * RS);       // per half [2][LH*RS]
+    f32x4* sAff = reinterpret_cast<f32x4*>(sS + (SC ? nblk * NT * TS : 0) + 4 * LH * RS) + half * 32;   // per half [2][16]
+    const int tid = threadIdx.x & 255, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = wave >> 1, px = wave & 1;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const bool has_aff = p.aff0 != nullptr;
+
+    // contiguous range of tiles, order (n, ty, tx)
+    const int chunk = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    int w_begin = blockIdx.x * chunk;
+    int w_end = min(p.total_tiles, w_begin + chunk);
+    if (w_begin >= w_end) return;                  // whole workgroup
+    const int first_half = (w_end - w_begin + 1) >> 1;
+    const int iters = first_half * nblk;           // loop trips of the longer half: both halves run the same barriers
+    if (half == 0) w_end = w_begin + first_half; else w_begin += first_half;
+    struct Tile { int n, y0, x0; };
+    auto advance = [&](const Tile& t) {
+        Tile u = t;
+        u.x0 += 16;
+        if (u.x0 == p.W) { u.x0 = 0; u.y0 += 16; if (u.y0 == p.H) { u.y0 = 0; u.n += 1; } }
+        return u;
+    };
+    auto is_edge = [&](const Tile& t) { return t.y0 == 0 || t.x0 == 0 || t.y0 + 16 == p.H || t.x0 + 16 == p.W; };
+    const int t_ly = tid / LW - 1, t_lx = tid % LW - 1;                 // input-tile coordinates of the staged pixel
+    const int t_lds = tid < LH * LW ? (tid / LW) * RS + (tid % LW) * PX : -1;
+    auto tile_pixel = [&](const Tile& t) {
+        TilePixel tp;
+        const int gy = (t.y0 >> 1) + t_ly, gx = (t.x0 >> 1) + t_lx;
+        const bool inside = t_lds >= 0 && (unsigned)gy < (unsigned)p.Hs && (unsigned)gx < (unsigned)p.Ws;
+        tp.lds = t_lds;
+        tp.pix = inside ? (t.n * p.Hs + gy) * p.Ws + gx : -1;
+        return tp;
+    };
+    int abase[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+        abase[mt] = ((mt >> 1) * 4 + (i16 >> 2) + 1) * RS + ((mt & 1) * 4 + (i16 & 3) + 1) * PX + kq * KQ;
+    const int bbase = (kq * 16 + i16) * KQ;
+    const int asc = ((wave >> 1) * 4 + (i16 >> 2) + 1) * RS + ((wave & 1) * 4 + (i16 & 3) + 1) * PX + kq * KQ;
+    f32x4 acc[4][NT];
+    f32x4 accs[SC ? NT : 1];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (SC) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- the weight panel (and the shortcut's) -> LDS, once
+    for (int cbk = 0; cbk < nblk; ++cbk) {
+        f32x4 rb[BIT];
+#pragma unroll
+        for (int j = 0; j < BIT; ++j) {
+            const int i = min((int)threadIdx.x + j * 512, NB4 - 1);
+            const int q = i / (SEG / 4), r = i % (SEG / 4);
+            rb[j] = reinterpret_cast<const f32x4*>(p.wpk + ((size_t)q * nblk + cbk) * SEG)[r];
+        }
+#pragma unroll
+        for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sW + cbk * NT * SEG)[min((int)threadIdx.x + j * 512, NB4 - 1)] = rb[j];
+        if (SC) {
+            f32x4 rs[SIT];
+#pragma unroll
+            for (int j = 0; j < SIT; ++j) {
+                const int i = min((int)threadIdx.x + j * 512, NT * TS / 4 - 1);
+                const int q = i / (TS / 4), r = i % (TS / 4);
+                rs[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)q * nblk + cbk) * TS)[r];
+            }
+#pragma unroll
+            for (int j = 0; j < SIT; ++j) reinterpret_cast<f32x4*>(sS + cbk * NT * TS)[min((int)threadIdx.x + j * 512, NT * TS / 4 - 1)] = rs[j];
+        }
+    }
+    // per-channel epilogue constants: one channel group, so they never change
+    float e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 16 + i16;
+        e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = 0.f;
+        if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
+        if (SC) scb[nt] = p.sc_bias[co];
+    }
+    const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;     // quad-transposed store layout
+    const unsigned lane_out = (unsigned)((2 * (lane >> 4) * p.W + 2 * xj) * p.Cout + cq4);
+    const unsigned lane_sc = (unsigned)(((lane >> 4) * p.Ws + xj) * p.Cout + cq4);
+
+    f32x4 ra[4], raff = {0.f, 0.f, 0.f, 0.f};
+    auto load_item = [&](const Tile& t, int cb, const TilePixel& tp) {
+        const bool first = cb < nblk0;
+        load_pixel(ra, first ? p.src0 : p.src1, first ? p.C0 : p.C1, (first ? cb : cb - nblk0) * 16, tp);
+        if (has_aff && first) raff = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0 + cb * 16)[tid & 15];
+    };
+    auto write_aff_item = [&](int slot) { if (has_aff && tid < 16) sAff[slot * 16 + tid] = raff; };
+    auto write_item = [&](int cb, const TilePixel& tp, bool edge, int buf) {
+        float* a_img = sA + buf * (LH * RS);
+        const float4* tab = reinterpret_cast<const float4*>(sAff) + buf * 16;
+        if (cb < nblk0 && has_aff) {
+            if (edge) store_pixel<true, BF, true>(a_img, ra, tab, tp);
+            else store_pixel<true, BF, false>(a_img, ra, tab, tp);
+        } else if (edge) store_pixel<false, BF, true>(a_img, ra, tab, tp);
+        else store_pixel<false, BF, false>(a_img, ra, tab, tp);
+    };
+    auto mfma_item = [&](int buf, int cb) {
+        const float* a_img = sA + buf * (LH * RS);
+        const float* b_img = sW + cb * (NT * SEG);
+        // valid taps of this parity class, ascending ky then kx:
+        //   py==0: ky=1 (dy 0), ky=3 (dy -1);   py==1: ky=0 (dy +1), ky=2 (dy 0)
+#pragma unroll
+        for (int jy = 0; jy < 2; ++jy) {
+            const int ky = (py ? 0 : 1) + 2 * jy;
+            const int dy = py ? (1 - jy) : -jy;
+#pragma unroll
+            for (int jx = 0; jx < 2; ++jx) {
+                const int kx = (px ? 0 : 1) + 2 * jx;
+                const int dx = px ? (1 - jx) : -jx;
+                const int toff = dy * RS + dx * PX;
+                const int tap = ky * 4 + kx;
+                if constexpr (BF) {
+                    s16x4 a[4], b[NT];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const s16x4*>(a_img + abase[mt] + toff);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const s16x4*>(b_img + bbase + nt * SEG + tap * TS);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                } else {
+                    f32x4 a[4], b[NT];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_img + abase[mt] + toff);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(b_img + bbase + nt * SEG + tap * 256);
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (SC && BF) {
+            const s16x4 as = *reinterpret_cast<const s16x4*>(a_img + asc);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                accs[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(as, *reinterpret_cast<const s16x4*>(sS + cb * (NT * TS) + bbase + nt * TS), accs[nt], 0, 0, 0);
+        } else if constexpr (SC) {
+            const f32x4 as = *reinterpret_cast<const f32x4*>(a_img + asc);
+            f32x4 bs[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bs[nt] = *reinterpret_cast<const f32x4*>(sS + cb * (NT * TS) + bbase + nt * 256);
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    accs[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[cg], bs[nt][cg], accs[nt], 0, 0, 0);
+        }
+    };
+    auto epilogue = [&](const Tile& t) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[mt][nt][r];
+                    if (EPI == EPI_DEC) {
+                        const float yv = v[r] + e0[nt];
+                        v[r] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
+                    }
+                }
+                const f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
+                const size_t ubase = ((size_t)(t.n * p.H + t.y0 + 8 * (mt >> 1) + py) * p.W + t.x0 + 8 * (mt & 1) + px) * p.Cout + nt * 16;
+                *reinterpret_cast<f32x4*>(p.out + ubase + lane_out) = vt;
+                acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (SC) {
+                const size_t ubase = ((size_t)(t.n * p.Hs + (t.y0 >> 1) + (wave >> 1) * 4) * p.Ws + (t.x0 >> 1) + (wave & 1) * 4) * p.Cout + nt * 16;
+                *reinterpret_cast<f32x4*>(p.out_sc + ubase + lane_sc) =
+                    quad_transpose(accs[nt][0] + scb[nt], accs[nt][1] + scb[nt], accs[nt][2] + scb[nt], accs[nt][3] + scb[nt], xj);
+                accs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+
+    // ---- items (tile, channel block): `tc/cb` is multiplied out of LDS buffer it&1, `tr/cbr` sits in registers
+    const int total_items = max(w_end - w_begin, 0) * nblk;      // of this half (the second one may have none)
+    Tile tc, tr;
+    {
+        const int tiles_y = p.H >> 4, w0 = min(w_begin, p.total_tiles - 1);
+        const int tx = w0 % p.tiles_x, r = w0 / p.tiles_x;
+        tc.x0 = tx * 16; tc.y0 = (r % tiles_y) * 16; tc.n = r / tiles_y;
+    }
+    int cb = 0, cbr = 0;
+    TilePixel tpr = tile_pixel(tc);
+    auto next_item = [&](int i, Tile& t, int& cbi, TilePixel& tp) {
+        if (i + 1 >= total_items) return;
+        if (++cbi == nblk) { cbi = 0; t = advance(t); tp = tile_pixel(t); }
+    };
+    load_item(tc, cb, tpr);
+    write_aff_item(0);
+    __syncthreads();                       // weight panel + entries of item 0 visible
+    if (total_items > 0) write_item(cb, tpr, is_edge(tc), 0);
+    tr = tc; cbr = cb;
+    next_item(0, tr, cbr, tpr);
+    load_item(tr, cbr, tpr);
+    write_aff_item(1);
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        if (it < total_items) {
+            if (it + 1 < total_items) write_item(cbr, tpr, is_edge(tr), (it + 1) & 1);
+            Tile t2 = tr; int cb2 = cbr;
+            next_item(it + 1, t2, cb2, tpr);
+            load_item(t2, cb2, tpr);
+            mfma_item(it & 1, cb);
+            if (cb == nblk - 1) epilogue(tc);
+            write_aff_item(it & 1);
+            tc = tr; cb = cbr; tr = t2; cbr = cb2;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Blur (depthwise 3x3, zero pad) -> AddNoise -> Bias -> LeakyReLU -> statistics.
 // One thread = one aligned quad of 4 consecutive x for 4 consecutive channels.
 __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
@@ -1879,12 +2128,59 @@ static hipError_t launch_subpixel_t(const ConvParams& p, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// persistent form with the LDS-resident weight panel (subpixel_res): one 512-thread workgroup per CU
+template <int NT, int EPI, bool SC, bool BF>
+static hipError_t launch_subpixel_res_t(const ConvParams& p, int n, size_t lds, hipStream_t s) {
+    auto kern = subpixel_res<NT, EPI, SC, BF>;
+    static bool attr_done = false;
+    static int num_cus = 0;
+    if (!attr_done) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    ConvParams q = p;
+    q.tiles_x = p.W / 16;
+    q.tiles_y = p.H / 16;
+    q.groups = 1;
+    q.total_tiles = q.tiles_x * q.tiles_y * n;
+    const int grid = std::min(num_cus, (q.total_tiles + 1) / 2);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, q);
+    return hipGetLastError();
+}
+
+// LDS bytes of subpixel_res for this layer, or 0 when the layer does not qualify (several channel groups, a
+// weight panel beyond ~100 KB, too few tiles to keep every CU busy)
+static size_t subpixel_res_lds(const ConvParams& p, int ct, bool sc, int n) {
+    static const bool enabled = !(getenv("GSA_SUBRES") && atoi(getenv("GSA_SUBRES")) == 0);
+    if (!enabled || ct != p.Cout || ct > 32) return 0;      // instantiated for 16 and 32 output channels
+    const int ts = p.bf16 ? 128 : 256, px = p.bf16 ? 8 : 16, rs = 10 * px + (p.bf16 ? 4 : 8);
+    const int nblk = (p.C0 + p.C1) / 16, nt = ct / 16;
+    const size_t lds = sizeof(float) * ((size_t)nblk * nt * 16 * ts + (sc ? (size_t)nblk * nt * ts : 0) + 4 * 10 * rs) + 64 * sizeof(float4);
+    const long tiles = (long)(p.H / 16) * (p.W / 16) * n;
+    if (lds > 128 * 1024 || tiles < 4096) return 0;
+    return lds;
+}
+
 // widest channel tile that still gives the chip >= 2 workgroups per CU (else the narrowest)
 static int subpixel_cout_tile(int H, int W, int Cout, int n) {
     const long tiles = (long)(H / 16) * (W / 16) * n;
     for (int ct = 64; ct >= 16; ct /= 2)
         if (Cout % ct == 0 && (tiles * (Cout / ct) >= 512 || ct == 16)) return ct;
     return 16;
+}
+
+// exact C++ name of the instantiation launch_subpixel picks (profile labels)
+const char* subpixel_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
+    static thread_local char buf[112];
+    const int ct = subpixel_cout_tile(p.H, p.W, p.Cout, n);
+    const bool res = subpixel_res_lds(p, ct, sc, n) != 0;
+    snprintf(buf, sizeof buf, "void gsa::%s<%d, %d, %s, %s>(gsa::ConvParams)", res ? "subpixel_res" : "subpixel_mfma", ct / 16, epi,
+             sc ? "true" : "false", p.bf16 ? "true" : "false");
+    return buf;
 }
 
 const char* subpixel_geom_name(int H, int W, int Cout, int n) {
@@ -1898,6 +2194,17 @@ hipError_t launch_subpixel(const ConvParams& p, int epi, bool sc, int n, hipStre
     if (p.H != 2 * p.Hs || p.W != 2 * p.Ws || p.H % 16 || p.W % 16 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
     if (sc && epi != EPI_DEC) return hipErrorInvalidValue;
     const int ct = subpixel_cout_tile(p.H, p.W, p.Cout, n);
+    if (const size_t rlds = subpixel_res_lds(p, ct, sc, n)) {
+#define GSA_SUBR(NT, BF) \
+        if (ct == 16 * NT && (p.bf16 != 0) == BF) { \
+            if (sc) return launch_subpixel_res_t<NT, EPI_DEC, true, BF>(p, n, rlds, s); \
+            if (epi == EPI_DEC) return launch_subpixel_res_t<NT, EPI_DEC, false, BF>(p, n, rlds, s); \
+            if (epi == EPI_RAW) return launch_subpixel_res_t<NT, EPI_RAW, false, BF>(p, n, rlds, s); \
+            return hipErrorInvalidValue; \
+        }
+        GSA_SUBR(1, false) GSA_SUBR(2, false) GSA_SUBR(1, true) GSA_SUBR(2, true)
+#undef GSA_SUBR
+    }
 #define GSA_SUB(NT) \
     if (ct == 16 * NT && !p.bf16) { \
         if (sc) return launch_subpixel_t<NT, EPI_DEC, true, false>(p, n, s); \
