@@ -2161,7 +2161,7 @@ static size_t subpixel_res_lds(const ConvParams& p, int ct, bool sc, int n) {
     const int nblk = (p.C0 + p.C1) / 16, nt = ct / 16;
     const size_t lds = sizeof(float) * ((size_t)nblk * nt * 16 * ts + (sc ? (size_t)nblk * nt * ts : 0) + 4 * 10 * rs) + 64 * sizeof(float4);
     const long tiles = (long)(p.H / 16) * (p.W / 16) * n;
-    if (lds > 128 * 1024 || tiles < 4096) return 0;
+    if (lds > 160 * 1024 || tiles < 4096) return 0;
     return lds;
 }
 
