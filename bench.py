@@ -22,6 +22,7 @@ if ROOT not in sys.path:
 GFLOP_PER_SAMPLE = {"ffhq": 126.44, "cars": 85.52, "bedrooms": 55.51}
 MB_PER_SAMPLE = {"ffhq": 1440.0, "cars": 623.2, "bedrooms": 234.4}
 PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (the headline figure with 2:1 sparsity is not used)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -221,8 +222,12 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "roofline": roofline,
             "whole_path": {
-                "fp32_tflops": round(GFLOP_PER_SAMPLE[args.gan] * value / 1e3, 2),
-                "fp32_frac_of_peak": round(GFLOP_PER_SAMPLE[args.gan] * value / 1e3 / world / PEAK_FP32_TFLOPS, 4),
+                # reference FLOPs per second; priced against the f32 MFMA peak, or the dense bf16 MFMA
+                # peak in bf16 mode
+                "tflops": round(GFLOP_PER_SAMPLE[args.gan] * value / 1e3, 2),
+                "mfma_peak_tflops": PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS,
+                "frac_of_mfma_peak": round(GFLOP_PER_SAMPLE[args.gan] * value / 1e3 / world /
+                                           (PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS), 4),
                 "algorithmic_hbm_gbs": round(MB_PER_SAMPLE[args.gan] * value / 1e3, 1),
                 "hbm_frac_of_peak": round(MB_PER_SAMPLE[args.gan] * value / 1e3 / world / PEAK_HBM_GBS, 4),
                 "kernel_ms_per_step": round(kms / args.steps, 3),
