@@ -1042,6 +1042,18 @@ int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const floa
     return run_decoder(c, s, n, fsrc, faff, nullptr, mask, ns, -1, false);
 }
 
+int gsa_segmentation_eval(gsa_ctx* c, void* stream, int32_t n, int32_t classes, int32_t H, int32_t W, const float* logits,
+                          const int8_t* labels, uint64_t* confusion, uint64_t* loss_fixed) {
+    if (!c) return GSA_ERR_INVALID;
+    if (n <= 0 || H <= 0 || W <= 0 || !logits || !labels || !confusion || !loss_fixed)
+        return fail(c, GSA_ERR_INVALID, "gsa_segmentation_eval: bad argument");
+    if (classes < 2 || classes > 8) return fail(c, GSA_ERR_INVALID, "gsa_segmentation_eval: 2..8 classes supported");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_seg_eval(logits, labels, n, classes, H, W, reinterpret_cast<unsigned long long*>(confusion),
+                            reinterpret_cast<unsigned long long*>(loss_fixed), (hipStream_t)stream));
+    return GSA_OK;
+}
+
 int gsa_set_overlap(gsa_ctx* c, int32_t levels) {
     if (!c) return GSA_ERR_INVALID;
     c->side_levels = levels < 0 ? 0 : levels;

@@ -1920,6 +1920,50 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* src0, int 
     if (mask) mask[(size_t)n * HW + pix] = (uint8_t)best;
 }
 
+// ------------------------------------------------------------------------------------------
+// Evaluation: confusion counts of argmax(logits) against integer labels (-1 = ignore) and the
+// weighted softmax cross-entropy of SegSolver.evaluate_for_data (weight 1 on labelled pixels, 0 on ignored).
+// Counts are exact integers; the loss is summed as rint(err * 2^32) in wrapping 64-bit integers, so the
+// result does not depend on the order of the atomics.
+template <int K>
+__global__ __launch_bounds__(256) void seg_eval_kernel(const float* logits, const int8_t* labels, int HW,
+                                                       unsigned long long* confusion, unsigned long long* loss_fixed) {
+    __shared__ unsigned cnt[K * K];
+    __shared__ unsigned long long lsum;
+    const int n = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < K * K; i += 256) cnt[i] = 0u;
+    if (tid == 0) lsum = 0ull;
+    __syncthreads();
+    unsigned long long my = 0ull;
+    for (int pix = blockIdx.x * 256 + tid; pix < HW; pix += gridDim.x * 256) {
+        const int l = labels[(size_t)n * HW + pix];
+        float v[K];
+#pragma unroll
+        for (int o = 0; o < K; ++o) v[o] = logits[((size_t)n * K + o) * HW + pix];
+        int best = 0;
+        float m = v[0];
+#pragma unroll
+        for (int o = 1; o < K; ++o)
+            if (v[o] > m) { m = v[o]; best = o; }
+        if (l >= 0 && l < K) {
+            atomicAdd(&cnt[l * K + best], 1u);
+            float se = 0.0f;
+#pragma unroll
+            for (int o = 0; o < K; ++o) se += expf(v[o] - m);
+            float vl = v[0];
+#pragma unroll
+            for (int o = 1; o < K; ++o) vl = l == o ? v[o] : vl;
+            const float err = (m + logf(se)) - vl;              // -log_softmax(v)[l]
+            my += to_fixed(err, 4294967296.0);
+        }
+    }
+    atomicAdd(&lsum, my);
+    __syncthreads();
+    for (int i = tid; i < K * K; i += 256)
+        if (cnt[i]) atomicAdd(&confusion[i], (unsigned long long)cnt[i]);
+    if (tid == 0 && lsum) atomicAdd(&loss_fixed[n], lsum);
+}
+
 // ========================================================================================
 // host-side launchers
 
@@ -2304,6 +2348,17 @@ hipError_t launch_final_conv(const float* src0, int C0, const float* src1, int C
         case 7: return launch_final_t<7>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
         case 8: return launch_final_t<8>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
     }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_seg_eval(const float* logits, const int8_t* labels, int n, int classes, int H, int W,
+                           unsigned long long* confusion, unsigned long long* loss_fixed, hipStream_t s) {
+    const int HW = H * W;
+    const dim3 grid(std::min((HW + 255) / 256, 1024), n);
+#define GSA_EVAL(K) \
+    if (classes == K) { hipLaunchKernelGGL(seg_eval_kernel<K>, grid, dim3(256), 0, s, logits, labels, HW, confusion, loss_fixed); return hipGetLastError(); }
+    GSA_EVAL(2) GSA_EVAL(3) GSA_EVAL(4) GSA_EVAL(5) GSA_EVAL(6) GSA_EVAL(7) GSA_EVAL(8)
+#undef GSA_EVAL
     return hipErrorInvalidValue;
 }
 

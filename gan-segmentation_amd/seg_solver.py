@@ -3,8 +3,8 @@
     solver = SegSolver(max_res_log2, path_to_data, checkpoints_dir, gpu_ids, keep_weights=False)
     if solver.is_trained: mask = solver.predict(features)    # (N,H,W,1) float32 in {0..K-1}
 
-Training (``fit``), evaluation and the few-shot dataset are outside the `generate` hot path
- and raise NotImplementedError.
+``evaluate`` (pixAcc / mIoU / weighted softmax-CE over annotated samples) runs on
+the device too.  Training (``fit``) stays outside the `generate` hot path and raises NotImplementedError.
 """
 import os
 
@@ -79,5 +79,71 @@ class SegSolver:
     def fit(self, *args, **kwargs):
         raise NotImplementedError("decoder training is outside the generate hot path (SURVEY.md section 8f)")
 
-    def evaluate(self, *args, **kwargs):
-        raise NotImplementedError("evaluation is outside the generate hot path (SURVEY.md section 8f)")
+    # -- evaluation ------------------------------------------------------
+    def evaluate_batch(self, features, labels, metric=None):
+        """One batch of reference ``evaluate_for_data`` (:229-262) on the device: decoder forward, weighted
+        softmax-CE and the confusion counts of ``SegmentationMetric.update``.  ``labels``: (N,H,W) integers,
+        -1 = ignore.  Returns (batch-mean loss, confusion (K,K) int64); updates ``metric`` when given."""
+        from ._runtime import current_stream_ptr
+        logits, _mask = self.net(*features, want_mask=True)
+        n, k, H, W = logits.shape
+        dev = logits.device
+        lab = torch.as_tensor(np.asarray(labels)).reshape(n, H, W).to(device=dev, dtype=torch.int8).contiguous()
+        conf = torch.zeros((k, k), dtype=torch.int64, device=dev)
+        loss_fixed = torch.zeros((n,), dtype=torch.int64, device=dev)
+        self.net._model.ctx.segmentation_eval(current_stream_ptr(dev), n, k, H, W, logits.data_ptr(), lab.data_ptr(),
+                                              conf.data_ptr(), loss_fixed.data_ptr())
+        conf_np = conf.cpu().numpy()
+        per_sample = loss_fixed.cpu().numpy().astype(np.float64) / 2.0 ** 32 / (H * W)
+        if metric is not None:
+            metric.update_confusion(conf_np)
+        return float(per_sample.mean()), conf_np
+
+    def evaluate(self, input_dir, output_dir=None):
+        """pixAcc / mIoU / loss over the annotated samples of ``input_dir`` (``feat_*.pickle`` + ``img_*.jpg`` +
+        ``mask_*.png``, reference seg_datasets.py) -> [('accuracy', v), ('mean-iou', v), ('total-loss', v)]
+        (reference :222-305).  Samples are evaluated one per batch (the reference's loss is the mean of
+        batch means, identical for full batches).  With ``output_dir`` the per-sample image, predicted mask
+        (255/128), ground truth (255/128/0) and a metrics line are written as the reference does."""
+        from . import annotation_io
+        from .metrics import SegmentationMetric
+        if not self.is_trained:
+            raise RuntimeError("train Decoder first! (no checkpoint loaded)")
+        names = sorted(f for f in os.listdir(input_dir) if f.endswith(".pickle") and "feat" in f)
+        if not names:
+            raise ValueError("number of eval samples should be > 0")     # reference :160-162
+        nclass = self.cfg["num_classes"]
+        metric = SegmentationMetric(nclass, skip_bg=True)
+        total_loss, total_cnt = 0.0, 0
+        if output_dir is not None:
+            os.makedirs(output_dir, exist_ok=True)
+        for fname in names:
+            image_id = int(os.path.splitext(fname)[0].split("_")[-1])
+            mask, img, feats = annotation_io.load_sample(input_dir, image_id)
+            if mask is None:
+                raise ValueError("no mask for %s" % fname)
+            loss_v, conf = self.evaluate_batch(feats, mask[None])
+            metric.update_confusion(conf)
+            total_loss += loss_v
+            total_cnt += 1
+            if output_dir is not None:
+                self._write_eval_sample(output_dir, image_id, img, feats, mask, conf, nclass)
+        result = metric.get_name_value()
+        result.append(("total-loss", total_loss / total_cnt if total_cnt else 0.0))
+        return result
+
+    def _write_eval_sample(self, output_dir, image_id, img, feats, mask, conf, nclass):
+        from PIL import Image
+        from .metrics import SegmentationMetric
+        m = SegmentationMetric(nclass, skip_bg=True)
+        m.update_confusion(conf)
+        metric_str = ", ".join("%s %.3f" % (name, v) for name, v in m.get_name_value())
+        pred = self.predict(feats)[0, :, :, 0].astype(np.int32)
+        pred_img = np.where(pred == 1, 255, np.where(pred == 0, 128, pred)).astype(np.uint8)
+        gt = np.where(mask == 1, 255, np.where(mask == 0, 128, 0)).astype(np.uint8)
+        imname = "img_%06d.jpg" % image_id
+        Image.fromarray(np.ascontiguousarray(img, np.uint8), "RGB").save(os.path.join(output_dir, imname))
+        Image.fromarray(pred_img, "L").save(os.path.join(output_dir, "mask_%06d.png" % image_id))
+        Image.fromarray(gt, "L").save(os.path.join(output_dir, "gt_mask_%06d.png" % image_id))
+        with open(os.path.join(output_dir, "metrics_%06d.txt" % image_id), "w") as fp:
+            fp.write(", ".join(str(w) for w in [imname, img.shape, pred_img.shape, gt.shape, metric_str]) + "\n")

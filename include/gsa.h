@@ -138,6 +138,20 @@ int gsa_set_overlap(gsa_ctx* ctx, int32_t levels);
 typedef enum { GSA_PREC_F32 = 0, GSA_PREC_BF16 = 1 } gsa_precision;
 int gsa_set_precision(gsa_ctx* ctx, int32_t mode);
 
+/* Per-batch arithmetic of SegSolver.evaluate_for_data (reference seg_solver.py:229-262) and
+ * SegmentationMetric.update (reference metrics.py:497-606), SURVEY.md section 8f-4:
+ *   logits     dev (N,classes,H,W) fp32 (gsa_decoder_forward's logits)
+ *   labels     dev (N,H,W) int8: class index, -1 = ignore (seg_datasets.py:85-106)
+ *   confusion  dev [classes*classes] u64, ACCUMULATED: confusion[l*classes+p] += #pixels with label l >= 0 and
+ *              argmax p (first maximum).  pixAcc / IoU follow from it: correct = trace, labelled = sum,
+ *              inter = diagonal, union = row sum + column sum - diagonal.
+ *   loss_fixed dev [N] u64, ACCUMULATED: sum over the sample's labelled pixels of rint(err * 2^32) with
+ *              err = -log_softmax(logits)[label] in fp32 (SoftmaxCELoss with sample weight 1 on labelled
+ *              pixels, 0 on ignored ones); the per-sample loss is loss_fixed / 2^32 / (H*W).
+ * Both buffers are caller-zeroed.  classes 2..8. */
+int gsa_segmentation_eval(gsa_ctx* ctx, void* stream, int32_t n, int32_t classes, int32_t H, int32_t W,
+                          const float* logits, const int8_t* labels, uint64_t* confusion, uint64_t* loss_fixed);
+
 /* --- measurement hooks (bench.py) ------------------------------------------------------ */
 
 /* When enabled every kernel launch is bracketed by hipEvents on the launch stream. */
