@@ -18,7 +18,7 @@ HIP_LIBRARY = os.path.join(_HERE, "csrc", "libgsa_hip.so")
 API_SYMBOLS = (
     "create", "destroy", "last_error", "generator_init", "generator_set_param",
     "generator_commit", "decoder_init", "decoder_set_param", "decoder_commit", "reserve",
-    "generator_forward", "decoder_forward", "generate", "set_overlap", "set_precision", "segmentation_eval",
+    "generator_forward", "decoder_forward", "generate", "set_overlap", "set_precision", "segmentation_eval", "fill_inputs",
     "profile_enable", "profile_collect",
     "profile_entry", "profile_reset", "version",
 )
@@ -73,6 +73,7 @@ class Api:
             "set_overlap": (c.c_int, [vp, i32]),
             "set_precision": (c.c_int, [vp, i32]),
             "segmentation_eval": (c.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+            "fill_inputs": (c.c_int, [vp, vp, i32, c.c_uint64, c.c_uint64, vp, c.POINTER(vp)]),
             "profile_enable": (c.c_int, [vp, i32]),
             "profile_collect": (c.c_int, [vp]),
             "profile_entry": (c.c_int, [vp, i32, c.POINTER(c.c_char_p), c.POINTER(c.c_double),
@@ -205,6 +206,10 @@ class Context:
         """"fp32" (default, bit-exact canonical path) or "bf16" (bf16 MFMA operands); before the weights are loaded."""
         self._check(self.api.set_precision(self._h, PRECISIONS[precision]), "set_precision")
         self.precision = precision
+
+    def fill_inputs(self, stream, n, seed, first_index, z=None, noise=None):
+        self._check(self.api.fill_inputs(self._h, stream, n, int(seed) & (2 ** 64 - 1), int(first_index), z,
+                                         _ptr_array(noise) if noise is not None else None), "fill_inputs")
 
     def segmentation_eval(self, stream, n, classes, H, W, logits, labels, confusion, loss_fixed):
         self._check(self.api.segmentation_eval(self._h, stream, n, classes, H, W, logits, labels, confusion, loss_fixed),

@@ -1042,6 +1042,24 @@ int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const floa
     return run_decoder(c, s, n, fsrc, faff, nullptr, mask, ns, -1, false);
 }
 
+int gsa_fill_inputs(gsa_ctx* c, void* stream, int32_t n, uint64_t seed, uint64_t first_index, float* z, float* const* noise) {
+    if (!c) return GSA_ERR_INVALID;
+    if (!c->g_init) return fail(c, GSA_ERR_STATE, "gsa_generator_init first");
+    if (n <= 0 || (!z && !noise)) return fail(c, GSA_ERR_INVALID, "gsa_fill_inputs: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (z) HIP_TRY(launch_fill_normal(z, c->gc.latent_size, n, first_index, 0xFFFFu, seed, s));
+    if (noise) {
+        const int planes = 2 * (c->gc.max_res_log2 - 1);
+        for (int l = 0; l < planes; ++l) {
+            if (!noise[l]) return fail(c, GSA_ERR_INVALID, "gsa_fill_inputs: null noise plane");
+            const int R = 4 << (l / 2);
+            HIP_TRY(launch_fill_normal(noise[l], R * R, n, first_index, (unsigned)l, seed, s));
+        }
+    }
+    return GSA_OK;
+}
+
 int gsa_segmentation_eval(gsa_ctx* c, void* stream, int32_t n, int32_t classes, int32_t H, int32_t W, const float* logits,
                           const int8_t* labels, uint64_t* confusion, uint64_t* loss_fixed) {
     if (!c) return GSA_ERR_INVALID;

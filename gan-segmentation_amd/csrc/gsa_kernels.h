@@ -85,6 +85,8 @@ hipError_t launch_final_conv(const float* src0, int C0, const float* src1, int C
 int conv_stat_rows(int H, int W, int Cout, int n);   // statistic partial rows per sample written by conv3x3 EPI_SYNTH
 int post_prow(int H, int W, int C);                  // ... written by the post kernel
 const char* subpixel_kernel_name(const ConvParams& p, int epi, bool sc, int n);
+hipError_t launch_fill_normal(float* out, int per_sample, int n, unsigned long long first_index, unsigned plane,
+                              unsigned long long seed, hipStream_t s);
 hipError_t launch_seg_eval(const float* logits, const int8_t* labels, int n, int classes, int H, int W,
                            unsigned long long* confusion, unsigned long long* loss_fixed, hipStream_t s);
 const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n);

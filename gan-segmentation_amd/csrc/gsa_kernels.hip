@@ -1964,6 +1964,46 @@ __global__ __launch_bounds__(256) void seg_eval_kernel(const float* logits, cons
     if (tid == 0 && lsum) atomicAdd(&loss_fixed[n], lsum);
 }
 
+// ------------------------------------------------------------------------------------------
+// Counter-based N(0,1) inputs: latents and AddNoise planes as a pure function of
+// (seed, global sample index, plane, element), so that a sample is the same bytes whatever batch, rank or GPU
+// count produces it.  Philox4x32-10 (Salmon et al., SC'11) + Box-Muller; the reference draws both from MXNet's
+// global RNG (image_generator.py:94, networks_stylegan.py:297-300), which has no such property.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// out: (n, per_sample) fp32, per_sample % 4 == 0; counter = (element quad, plane, sample index lo, hi), key = seed
+__global__ __launch_bounds__(256) void fill_normal_kernel(float* out, int per_sample, int n, unsigned long long first_index,
+                                                          unsigned plane, unsigned long long seed) {
+    const int quads = per_sample >> 2;
+    const long total = (long)n * quads;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int smp = (int)(i / quads), q = (int)(i - (long)smp * quads);
+        const unsigned long long idx = first_index + (unsigned long long)smp;
+        unsigned c[4] = {(unsigned)q, plane, (unsigned)idx, (unsigned)(idx >> 32)};
+        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        float v[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * 5.9604644775390625e-8f;       // (0,1), 24 bits
+            const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+            const float r = sqrtf(-2.0f * logf(u1));
+            const float a = 6.283185307179586f * u2;
+            v[2 * h] = r * cosf(a);
+            v[2 * h + 1] = r * sinf(a);
+        }
+        *reinterpret_cast<float4*>(out + (size_t)smp * per_sample + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // ========================================================================================
 // host-side launchers
 
@@ -2360,6 +2400,15 @@ hipError_t launch_seg_eval(const float* logits, const int8_t* labels, int n, int
     GSA_EVAL(2) GSA_EVAL(3) GSA_EVAL(4) GSA_EVAL(5) GSA_EVAL(6) GSA_EVAL(7) GSA_EVAL(8)
 #undef GSA_EVAL
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_fill_normal(float* out, int per_sample, int n, unsigned long long first_index, unsigned plane,
+                              unsigned long long seed, hipStream_t s) {
+    if (per_sample % 4 || per_sample <= 0 || n <= 0) return hipErrorInvalidValue;
+    const long total = (long)n * (per_sample / 4);
+    const int grid = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(fill_normal_kernel, dim3(grid), dim3(256), 0, s, out, per_sample, n, first_index, plane, seed);
+    return hipGetLastError();
 }
 
 }  // namespace gsa

@@ -128,6 +128,12 @@ class ImageGenerator:
                     yield img, fs
 
     # -- fused hot path ---------------------------------------------------------------------
+    def generate_indexed(self, first_index, n, seed=0, out=None):
+        """``generate_batch`` for the global samples ``first_index .. first_index+n-1`` with counter-based latents
+        and noise (``Generator.draw_indexed``): the dataset does not depend on how it is sharded."""
+        z, noise = self.netG.draw_indexed(first_index, n, seed)
+        return self.generate_batch(z, noise, out=out)
+
     def generate_batch(self, z, noise=None, out=None):
         """latents (N,512) [+ noise planes] -> (img (N,R,R,3) u8, mask (N,R,R) u8) on the GPU.
         The per-batch body of ``main.py generate`` (reference main.py:97-99) in one call.

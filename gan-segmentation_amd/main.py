@@ -33,6 +33,7 @@ def generate(cfg, limit=None, workers=None):
     gpu = gpu_ids[local_rank % len(gpu_ids)] if world == 1 and gpu_ids else local_rank
     n_generate = cfg.get("GENERATE_NUM", 10000) if limit is None else limit
     batch = cfg["GAN_BATCH_SIZE_PER_GPU"]
+    seed = int(cfg.get("SEED", 0))             # additive key: seed of the counter-based latents/noise
     precision = cfg.get("PRECISION", "fp32")   # additive key: "bf16" = bf16 MFMA operands (BASELINE config 5)
 
     solver = SegSolver(GAN_MAX_RES_LOG2[gan], os.path.join(root_dir, "data"), os.path.join(root_dir, "checkpoints"),
@@ -52,7 +53,8 @@ def generate(cfg, limit=None, workers=None):
     with DatasetWriter(dst_dir, workers=workers) as writer:
         while index < hi:
             bs = min(batch, hi - index)
-            img, mask = netG.generate_batch(netG.draw_latents(bs))
+            # latents and noise keyed on the global sample index: the files are the same for any number of ranks
+            img, mask = netG.generate_indexed(index, bs, seed=seed)
             writer.submit(img, mask, index)
             index += bs
     torch.cuda.synchronize()

@@ -72,6 +72,18 @@ class Generator:
             self._fixed_noise = noise
         return noise
 
+    def draw_indexed(self, first_index, n, seed=0):
+        """(z (n,latent), [noise planes]) on the device as a pure function of (seed, global sample index): sample
+        ``first_index + k`` gets the same bytes whatever batch, rank or GPU count asks for it (``gsa_fill_inputs``,
+        Philox4x32-10 + Box-Muller)."""
+        if not self._loaded:
+            raise RuntimeError("Generator parameters are not loaded")
+        dev = self._model.device
+        z = torch.empty((n, self.latent_size), device=dev, dtype=torch.float32)
+        noise = [torch.empty(s, device=dev, dtype=torch.float32) for s in self.noise_shapes(n)]
+        self._model.ctx.fill_inputs(current_stream_ptr(dev), n, seed, first_index, z.data_ptr(), [a.data_ptr() for a in noise])
+        return z, noise
+
     def _prepare(self, z, noise):
         if not self._loaded:
             raise RuntimeError("Generator parameters are not loaded")

@@ -138,6 +138,15 @@ int gsa_set_overlap(gsa_ctx* ctx, int32_t levels);
 typedef enum { GSA_PREC_F32 = 0, GSA_PREC_BF16 = 1 } gsa_precision;
 int gsa_set_precision(gsa_ctx* ctx, int32_t mode);
 
+/* Counter-based N(0,1) inputs: z (N,latent_size) and/or the 2*(max_res_log2-1) noise planes (N,1,R,R), each
+ * element a pure function of (seed, first_index + sample, plane, element) -- Philox4x32-10 + Box-Muller -- so a
+ * sample's inputs do not depend on the batch, rank or GPU count that produces it.
+ * Replaces mx.nd.random.randn (reference image_generator.py:94) and AddNoise's random_normal
+ * (networks_stylegan.py:297-300) when the caller wants reproducible shards; latent_size % 4 == 0.
+ * Either pointer may be NULL. */
+int gsa_fill_inputs(gsa_ctx* ctx, void* stream, int32_t n, uint64_t seed, uint64_t first_index, float* z,
+                    float* const* noise);
+
 /* Per-batch arithmetic of SegSolver.evaluate_for_data (reference seg_solver.py:229-262) and
  * SegmentationMetric.update (reference metrics.py:497-606), SURVEY.md section 8f-4:
  *   logits     dev (N,classes,H,W) fp32 (gsa_decoder_forward's logits)

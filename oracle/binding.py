@@ -28,7 +28,7 @@ def api():
         if not os.path.exists(ORACLE_LIBRARY):
             build()
         _api = _lib.Api(ORACLE_LIBRARY, "gsao_",
-                        optional=("set_overlap", "segmentation_eval", "profile_enable", "profile_collect", "profile_entry", "profile_reset"))
+                        optional=("set_overlap", "segmentation_eval", "fill_inputs", "profile_enable", "profile_collect", "profile_entry", "profile_reset"))
     return _api
 
 
