@@ -881,9 +881,11 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 cp.noise = nz; cp.nscale = B.nscale[1]; cp.nbias = B.nbias[1]; cp.partials = c->partials; cp.acc = c->stat_acc;
                 snprintf(layer, sizeof layer, "g.%d.conv_2", R);
                 const bool ws = conv_uses_ws(cp, EPI_SYNTH, false, n);
+                int rows = conv_stat_rows(R, R, C, n);
+                cp.stat_rows_host = &rows;            // the launcher may sum straight into stat_acc (rows = 0)
                 Launch lp(c, s, ws ? "void gsa::conv3x3_ws<ws, 1>(gsa::ConvParams)" : conv_kernel_name(cp, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
-                prow = ws ? 0 : conv_stat_rows(R, R, C, n);
+                prow = ws ? 0 : rows;
             }
             FinalizeParams fp{};
             fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C; fp.acc = c->stat_acc; fp.tickets = c->stat_tickets;

@@ -38,6 +38,8 @@ struct ConvParams {
     // fused 1x1 shortcut of DecoderResBlock (second output)
     const float* wsc; const float* sc_bias; float* out_sc;
     int tiles_x, tiles_y, groups, total_tiles;   // filled by the launcher
+    int stats_direct;                            // filled by the launcher: EPI_SYNTH sums go to acc with atomics (no partial rows)
+    int* stat_rows_host;                         // host pointer or null: the launcher reports the partial rows it used (0 = direct)
     int w_resident;                              // filled by the launcher: whole weight panel LDS-resident (conv3x3 DB form)
     unsigned long long* stamps;   // diagnostic build (-DGSA_STAMP) only: per-phase cycle sums
     int dbg;                      // diagnostic build only: bit0 = stage pixel 0 everywhere (timing of a cache-resident input)

@@ -409,6 +409,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
         }
     };
 
+    // Direct statistics (launcher: persistent double-buffered EPI_SYNTH launches): a wave keeps its fixed-point
+    // sums in registers across the tiles of one (sample, channel group) and adds them to acc[n][c] with one
+    // 64-bit atomic per channel when the group changes -- instead of a 16-byte partial row per tile and wave
+    // (16384 rows per sample at 1024^2, which finalize_kernel then needed 53 us to re-read).
+    const bool stats_direct = EPI == EPI_SYNTH && p.stats_direct;
+    unsigned long long dI1[NT], dI2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dI1[nt] = dI2[nt] = 0ull;
+    auto flush_stats = [&](const WorkTile& t) {      // t: any tile of the (sample, group) the sums belong to
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            unsigned long long I1 = dI1[nt], I2 = dI2[nt];
+            I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
+            I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
+            if (lane < 16) {
+                StatPart* a = p.acc + (size_t)t.n * p.Cout + t.g * COUT_T + (wn * NT + nt) * 16 + i16;
+                atomicAdd(&a->s1, I1);
+                atomicAdd(&a->s2, I2);
+            }
+            dI1[nt] = dI2[nt] = 0ull;
+        }
+    };
+
     auto epilogue = [&](const WorkTile& tc) {
             // ---- epilogue of tile tc (after epilogue_loads(tc)).  C layout: lane -> (channel = lane&15,
             // patch row = lane>>4), reg -> patch column.
@@ -457,7 +480,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
                     acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (SC) accs[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                if (EPI == EPI_SYNTH) {
+                if (EPI == EPI_SYNTH && stats_direct) {
+                    dI1[nt] += I1; dI2[nt] += I2;
+                } else if (EPI == EPI_SYNTH) {
                     I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
                     I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
                     if (lane < 16) {
@@ -590,7 +615,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
             TSUM(s0, k1, ka); TSUM(s1, ka, kb); TSUM(s2, kb, k2);
             mfma_item(it & 1, cb);
             TICK(k3);
-            if (cb == nblk - 1) epilogue(tc);
+            if (cb == nblk - 1) {
+                epilogue(tc);
+                if (stats_direct && (it + 1 >= total_items || tr.n != tc.n || tr.g != tc.g)) flush_stats(tc);
+            }
             TICK(k4);
             write_aff_item(it & 1);        // entries of item it+2 (loaded above) -> the slot item it used; read after the barrier
             __syncthreads();
@@ -2098,6 +2126,8 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     // prologue); long tiles pipeline inside the tile already and run ~8 % faster one tile per workgroup
     const bool persistent = (p.C0 + p.C1) <= 32 && q.total_tiles > num_cus * wgs_per_cu;
     const int grid = persistent ? num_cus * wgs_per_cu : q.total_tiles;
+    q.stats_direct = (EPI == EPI_SYNTH && NBUF == 2 && persistent && p.acc != nullptr) ? 1 : 0;
+    if (p.stat_rows_host) *p.stat_rows_host = q.stats_direct ? 0 : q.prow;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, s, q);
     return hipGetLastError();
 }
