@@ -1609,7 +1609,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p, int row
         const int r0 = blockIdx.z * rows_per_block;
         const int r1 = min(p.prow, r0 + rows_per_block);
         const StatPart* base = p.partials + (size_t)n * p.prow * p.C + c;
-        for (int r = r0 + rg; r < r1; r += nrg) {
+#pragma unroll 4
+        for (int r = r0 + rg; r < r1; r += nrg) {      // independent loads: keep several in flight
             const StatPart sp = base[(size_t)r * p.C];
             I1 += sp.s1; I2 += sp.s2;
         }
@@ -2347,7 +2348,9 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
 }
 
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s) {
-    const int rpb = 256;
+    // ~16 blocks per (sample, channel group): more blocks contend on the same few atomics (C = 16: 16 addresses),
+    // fewer leave each thread a long serial chain of row loads
+    const int rpb = std::min(256, std::max(64, (p.prow + 15) / 16));
     const int zb = (p.prow + rpb - 1) / rpb;   // prow == 0: the producer already summed into acc
     dim3 grid((p.C + 63) / 64, n, zb < 1 ? 1 : zb);
     hipLaunchKernelGGL(finalize_kernel, grid, dim3(256), 0, s, p, rpb);
