@@ -1256,21 +1256,24 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 // the activation image is double buffered (one barrier per item) and the loads of item i+2 fly during the
 // MFMAs of item i -- the structure of conv3x3_mfma's double-buffered form.  Arithmetic order per output is
 // unchanged (bit-identical results).
-template <int NT, int EPI, bool SC, bool BF>
+// KB = 16-channel blocks per item (2 when the block count is even: half as many workgroup barriers per MFMA).
+template <int NT, int EPI, bool SC, bool BF, int KB>
 __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     constexpr int PX = BF ? 8 : 16, TS = BF ? 128 : 256, KQ = BF ? 2 : 4;
     constexpr int LH = 10, LW = 10, RS = LW * PX + (BF ? 4 : 8);
     constexpr int SEG = 16 * TS, NB4 = NT * SEG / 4, BIT = (NB4 + 511) / 512;
     constexpr int SIT = (NT * TS / 4 + 511) / 512;
     const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4;
+    const int nitem = nblk / KB;                   // items per tile
+    constexpr int AB = KB * LH * RS;               // one activation buffer: KB block images
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // The workgroup is two halves of 4 waves (one CU holds one workgroup, every SIMD one wave of each half): each
     // half walks its own tiles through its own double-buffered activation image, both read the ONE weight panel.
     const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
     float* sW = smem;                              // [nblk][q][tap16][ci][16][cg]
     float* sS = sW + nblk * NT * SEG;              // SC: [nblk][q][ci][16][cg]
-    float* sA = sS + (SC ? nblk * NT * TS : 0) + half * (2 * LH * RS);       // per half [2][LH*RS]
-    f32x4* sAff = reinterpret_cast<f32x4*>(sS + (SC ? nblk * NT * TS : 0) + 4 * LH * RS) + half * 32;   // per half [2][16]
+    float* sA = sS + (SC ? nblk * NT * TS : 0) + half * (2 * AB);            // per half [2][KB][LH*RS]
+    f32x4* sAff = reinterpret_cast<f32x4*>(sS + (SC ? nblk * NT * TS : 0) + 4 * AB) + half * (2 * KB * 16);   // per half [2][KB][16]
     const int tid = threadIdx.x & 255, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int py = wave >> 1, px = wave & 1;
@@ -1283,7 +1286,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     int w_end = min(p.total_tiles, w_begin + chunk);
     if (w_begin >= w_end) return;                  // whole workgroup
     const int first_half = (w_end - w_begin + 1) >> 1;
-    const int iters = first_half * nblk;           // loop trips of the longer half: both halves run the same barriers
+    const int iters = first_half * nitem;          // loop trips of the longer half: both halves run the same barriers
     if (half == 0) w_end = w_begin + first_half; else w_begin += first_half;
     struct Tile { int n, y0, x0; };
     auto advance = [&](const Tile& t) {
@@ -1356,24 +1359,39 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     const unsigned lane_out = (unsigned)((2 * (lane >> 4) * p.W + 2 * xj) * p.Cout + cq4);
     const unsigned lane_sc = (unsigned)(((lane >> 4) * p.Ws + xj) * p.Cout + cq4);
 
-    f32x4 ra[4], raff = {0.f, 0.f, 0.f, 0.f};
-    auto load_item = [&](const Tile& t, int cb, const TilePixel& tp) {
-        const bool first = cb < nblk0;
-        load_pixel(ra, first ? p.src0 : p.src1, first ? p.C0 : p.C1, (first ? cb : cb - nblk0) * 16, tp);
-        if (has_aff && first) raff = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0 + cb * 16)[tid & 15];
+    f32x4 ra[KB][4], raff[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) raff[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_item = [&](const Tile& t, int ci, const TilePixel& tp) {      // item ci of tile t = blocks ci*KB .. +KB-1
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int cb = ci * KB + kb;
+            const bool first = cb < nblk0;
+            load_pixel(ra[kb], first ? p.src0 : p.src1, first ? p.C0 : p.C1, (first ? cb : cb - nblk0) * 16, tp);
+            if (has_aff && first) raff[kb] = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0 + cb * 16)[tid & 15];
+        }
     };
-    auto write_aff_item = [&](int slot) { if (has_aff && tid < 16) sAff[slot * 16 + tid] = raff; };
-    auto write_item = [&](int cb, const TilePixel& tp, bool edge, int buf) {
-        float* a_img = sA + buf * (LH * RS);
-        const float4* tab = reinterpret_cast<const float4*>(sAff) + buf * 16;
-        if (cb < nblk0 && has_aff) {
-            if (edge) store_pixel<true, BF, true>(a_img, ra, tab, tp);
-            else store_pixel<true, BF, false>(a_img, ra, tab, tp);
-        } else if (edge) store_pixel<false, BF, true>(a_img, ra, tab, tp);
-        else store_pixel<false, BF, false>(a_img, ra, tab, tp);
+    auto write_aff_item = [&](int slot) {
+        if (has_aff && tid < 16) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) sAff[(slot * KB + kb) * 16 + tid] = raff[kb];
+        }
     };
-    auto mfma_item = [&](int buf, int cb) {
-        const float* a_img = sA + buf * (LH * RS);
+    auto write_item = [&](int ci, const TilePixel& tp, bool edge, int buf) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int cb = ci * KB + kb;
+            float* a_img = sA + buf * AB + kb * (LH * RS);
+            const float4* tab = reinterpret_cast<const float4*>(sAff) + (buf * KB + kb) * 16;
+            if (cb < nblk0 && has_aff) {
+                if (edge) store_pixel<true, BF, true>(a_img, ra[kb], tab, tp);
+                else store_pixel<true, BF, false>(a_img, ra[kb], tab, tp);
+            } else if (edge) store_pixel<false, BF, true>(a_img, ra[kb], tab, tp);
+            else store_pixel<false, BF, false>(a_img, ra[kb], tab, tp);
+        }
+    };
+    auto mfma_block = [&](int buf, int kb, int cb) {
+        const float* a_img = sA + buf * AB + kb * (LH * RS);
         const float* b_img = sW + cb * (NT * SEG);
         // valid taps of this parity class, ascending ky then kx:
         //   py==0: ky=1 (dy 0), ky=3 (dy -1);   py==1: ky=0 (dy +1), ky=2 (dy 0)
@@ -1431,6 +1449,10 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
                     accs[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[cg], bs[nt][cg], accs[nt], 0, 0, 0);
         }
     };
+    auto mfma_item = [&](int buf, int ci) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) mfma_block(buf, kb, ci * KB + kb);
+    };
     auto epilogue = [&](const Tile& t) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -1460,7 +1482,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     };
 
     // ---- items (tile, channel block): `tc/cb` is multiplied out of LDS buffer it&1, `tr/cbr` sits in registers
-    const int total_items = max(w_end - w_begin, 0) * nblk;      // of this half (the second one may have none)
+    const int total_items = max(w_end - w_begin, 0) * nitem;     // of this half (the second one may have none)
     Tile tc, tr;
     {
         const int tiles_y = p.H >> 4, w0 = min(w_begin, p.total_tiles - 1);
@@ -1471,7 +1493,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     TilePixel tpr = tile_pixel(tc);
     auto next_item = [&](int i, Tile& t, int& cbi, TilePixel& tp) {
         if (i + 1 >= total_items) return;
-        if (++cbi == nblk) { cbi = 0; t = advance(t); tp = tile_pixel(t); }
+        if (++cbi == nitem) { cbi = 0; t = advance(t); tp = tile_pixel(t); }
     };
     load_item(tc, cb, tpr);
     write_aff_item(0);
@@ -1489,7 +1511,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
             next_item(it + 1, t2, cb2, tpr);
             load_item(t2, cb2, tpr);
             mfma_item(it & 1, cb);
-            if (cb == nblk - 1) epilogue(tc);
+            if (cb == nitem - 1) epilogue(tc);
             write_aff_item(it & 1);
             tc = tr; cb = cbr; tr = t2; cbr = cb2;
         }
@@ -2243,10 +2265,13 @@ static hipError_t launch_subpixel_t(const ConvParams& p, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// channel blocks per item of subpixel_res: 2 when the block count is even and the doubled activation buffers still fit
+static int subpixel_res_kb(const ConvParams& p);
+
 // persistent form with the LDS-resident weight panel (subpixel_res): one 512-thread workgroup per CU
-template <int NT, int EPI, bool SC, bool BF>
-static hipError_t launch_subpixel_res_t(const ConvParams& p, int n, size_t lds, hipStream_t s) {
-    auto kern = subpixel_res<NT, EPI, SC, BF>;
+template <int NT, int EPI, bool SC, bool BF, int KB>
+static hipError_t launch_subpixel_res_k(const ConvParams& p, int n, size_t lds, hipStream_t s) {
+    auto kern = subpixel_res<NT, EPI, SC, BF, KB>;
     static bool attr_done = false;
     static int num_cus = 0;
     if (!attr_done) {
@@ -2267,6 +2292,12 @@ static hipError_t launch_subpixel_res_t(const ConvParams& p, int n, size_t lds, 
     return hipGetLastError();
 }
 
+template <int NT, int EPI, bool SC, bool BF>
+static hipError_t launch_subpixel_res_t(const ConvParams& p, int n, size_t lds, hipStream_t s) {
+    return subpixel_res_kb(p) == 2 ? launch_subpixel_res_k<NT, EPI, SC, BF, 2>(p, n, lds, s)
+                                   : launch_subpixel_res_k<NT, EPI, SC, BF, 1>(p, n, lds, s);
+}
+
 // LDS bytes of subpixel_res for this layer, or 0 when the layer does not qualify (several channel groups, a
 // weight panel beyond ~100 KB, too few tiles to keep every CU busy)
 static size_t subpixel_res_lds(const ConvParams& p, int ct, bool sc, int n) {
@@ -2274,10 +2305,23 @@ static size_t subpixel_res_lds(const ConvParams& p, int ct, bool sc, int n) {
     if (!enabled || ct != p.Cout || ct > 32) return 0;      // instantiated for 16 and 32 output channels
     const int ts = p.bf16 ? 128 : 256, px = p.bf16 ? 8 : 16, rs = 10 * px + (p.bf16 ? 4 : 8);
     const int nblk = (p.C0 + p.C1) / 16, nt = ct / 16;
-    const size_t lds = sizeof(float) * ((size_t)nblk * nt * 16 * ts + (sc ? (size_t)nblk * nt * ts : 0) + 4 * 10 * rs) + 64 * sizeof(float4);
+    const size_t fixed = sizeof(float) * ((size_t)nblk * nt * 16 * ts + (sc ? (size_t)nblk * nt * ts : 0));
     const long tiles = (long)(p.H / 16) * (p.W / 16) * n;
-    if (lds > 160 * 1024 || tiles < 4096) return 0;
-    return lds;
+    if (tiles < 4096) return 0;
+    for (int kb = (nblk % 2 == 0 && nblk >= 4) ? 2 : 1; kb >= 1; --kb) {     // two blocks per item pay off from 4 blocks on
+        const size_t lds = fixed + sizeof(float) * 4 * kb * 10 * rs + 64 * kb * sizeof(float4);
+        if (lds <= 160 * 1024) return lds;
+    }
+    return 0;
+}
+
+static int subpixel_res_kb(const ConvParams& p) {
+    const int ts = p.bf16 ? 128 : 256, px = p.bf16 ? 8 : 16, rs = 10 * px + (p.bf16 ? 4 : 8);
+    const int nblk = (p.C0 + p.C1) / 16, nt = p.Cout / 16;
+    const bool sc = p.wsc != nullptr;
+    const size_t fixed = sizeof(float) * ((size_t)nblk * nt * 16 * ts + (sc ? (size_t)nblk * nt * ts : 0));
+    if (nblk % 2 || nblk < 4) return 1;
+    return fixed + sizeof(float) * 4 * 2 * 10 * rs + 128 * sizeof(float4) <= 160 * 1024 ? 2 : 1;
 }
 
 // widest channel tile that still gives the chip >= 2 workgroups per CU (else the narrowest)
@@ -2293,8 +2337,12 @@ const char* subpixel_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     static thread_local char buf[112];
     const int ct = subpixel_cout_tile(p.H, p.W, p.Cout, n);
     const bool res = subpixel_res_lds(p, ct, sc, n) != 0;
-    snprintf(buf, sizeof buf, "void gsa::%s<%d, %d, %s, %s>(gsa::ConvParams)", res ? "subpixel_res" : "subpixel_mfma", ct / 16, epi,
-             sc ? "true" : "false", p.bf16 ? "true" : "false");
+    if (res)
+        snprintf(buf, sizeof buf, "void gsa::subpixel_res<%d, %d, %s, %s, %d>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
+                 p.bf16 ? "true" : "false", subpixel_res_kb(p));
+    else
+        snprintf(buf, sizeof buf, "void gsa::subpixel_mfma<%d, %d, %s, %s>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
+                 p.bf16 ? "true" : "false");
     return buf;
 }
 
