@@ -1,0 +1,433 @@
+// Decoder-training operators for gfx950 behind the C ABI include/gsa_train.h.
+//
+// Training the reference's decoder is a few annotated images at batch size 1 for 24 epochs
+// (seg_solver.py:83-132): throughput is irrelevant next to the generate path, so these kernels are plain
+// LDS-tiled vector-ALU code in the reference's own NCHW / OIHW layouts -- one kernel serves the forward
+// convolution and, with the weight read transposed and flipped, its input gradient; a second one the weight
+// gradient.  Nothing here is shared with the inference kernels, and nothing here is order-canonical.
+//
+//   conv_kernel<K>      nn.Conv2D 3x3 / 1x1 (+ concat, + nearest x2 on read) and its dgrad   networks_seg.py:14-41,68,91
+//   wgrad_kernel<K>     dL/dW, dL/db of the same convolution                                  (autograd)
+//   bn_*                nn.BatchNorm (training mode) + LeakyReLU(0.2) + Dropout mask          networks_seg.py:17-32,69-78
+//   softmax_ce_kernel   SoftmaxCELoss(axis=1) with sample weights                             seg_solver.py:395-407
+//   adam_kernel         mx.optimizer.Adam                                                     seg_solver.py:203-219
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+
+#include "../../include/gsa_train.h"
+
+namespace {
+
+constexpr int GSA_OK_ = 0, GSA_ERR_INVALID_ = -1, GSA_ERR_HIP_ = -4;
+
+#define TRY_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "gsa_train: %s -> %s\n", #expr, hipGetErrorString(e_)); return GSA_ERR_HIP_; } } while (0)
+
+__device__ __forceinline__ float lrelu02(float v) { return v > 0.0f ? v : 0.2f * v; }
+
+// ---- convolution (forward / input gradient) ---------------------------------------------------
+struct ConvArgs {
+    const float* x0; const float* x1; int C0, C1, Hs, Ws, up, H, W;
+    const float* w; int Cout, transposed; const float* bias;
+    float* out0; int Cout0; float* out1; int accumulate;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+    constexpr int P = K / 2, LT = 16 + 2 * P, CI_B = 8, CO_B = 16, KK = K * K;
+    __shared__ float tile[CI_B][LT][LT + 1];
+    __shared__ float wsm[CI_B][KK][CO_B];
+    const int tiles_x = (a.W + 15) / 16;
+    const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+    const int o0 = blockIdx.y * CO_B, n = blockIdx.z;
+    const int tid = threadIdx.x, ly = tid / 16, lx = tid % 16;
+    const int Cin = a.C0 + a.C1;
+    float acc[CO_B];
+#pragma unroll
+    for (int o = 0; o < CO_B; ++o) acc[o] = 0.0f;
+    for (int c0 = 0; c0 < Cin; c0 += CI_B) {
+        for (int i = tid; i < CI_B * LT * LT; i += 256) {
+            const int c = i / (LT * LT), r = i % (LT * LT), yy = r / LT, xx = r % LT;
+            const int gy = ty0 - P + yy, gx = tx0 - P + xx, cc = c0 + c;
+            float v = 0.0f;
+            if (cc < Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const bool first = cc < a.C0;
+                const float* src = first ? a.x0 : a.x1;
+                const int Cs = first ? a.C0 : a.C1, cs = first ? cc : cc - a.C0;
+                v = src[(((size_t)n * Cs + cs) * a.Hs + (gy >> a.up)) * a.Ws + (gx >> a.up)];
+            }
+            tile[c][yy][xx] = v;
+        }
+        for (int i = tid; i < CI_B * KK * CO_B; i += 256) {
+            const int o = i % CO_B, t = (i / CO_B) % KK, c = i / (CO_B * KK);
+            const int oo = o0 + o, cc = c0 + c;
+            float v = 0.0f;
+            if (oo < a.Cout && cc < Cin)
+                v = a.transposed ? a.w[((size_t)cc * a.Cout + oo) * KK + (KK - 1 - t)] : a.w[((size_t)oo * Cin + cc) * KK + t];
+            wsm[c][t][o] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CI_B; ++c)
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                const float v = tile[c][ly + t / K][lx + t % K];
+#pragma unroll
+                for (int o = 0; o < CO_B; ++o) acc[o] = fmaf(v, wsm[c][t][o], acc[o]);
+            }
+        __syncthreads();
+    }
+    const int y = ty0 + ly, x = tx0 + lx;
+    if (y >= a.H || x >= a.W) return;
+#pragma unroll
+    for (int o = 0; o < CO_B; ++o) {
+        const int oo = o0 + o;
+        if (oo >= a.Cout) break;
+        float v = acc[o] + (a.bias ? a.bias[oo] : 0.0f);
+        float* dst = oo < a.Cout0 ? a.out0 + (((size_t)n * a.Cout0 + oo) * a.H + y) * a.W + x
+                                  : a.out1 + (((size_t)n * (a.Cout - a.Cout0) + (oo - a.Cout0)) * a.H + y) * a.W + x;
+        if (a.accumulate) v += *dst;
+        *dst = v;
+    }
+}
+
+// ---- weight / bias gradient ---------------------------------------------------------------------
+struct WgradArgs {
+    const float* x0; const float* x1; int C0, C1, Hs, Ws, up, H, W;
+    const float* dy; int Cout; float* dw; float* db;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int P = K / 2, LT = 16 + 2 * P, KK = K * K, OB = 16, CB = 16;
+    __shared__ float dyt[OB][256];
+    __shared__ float xt[CB][LT][LT + 1];
+    const int tiles_x = (a.W + 15) / 16;
+    const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+    const int Cin = a.C0 + a.C1, ncb = (Cin + CB - 1) / CB;
+    const int o0 = (blockIdx.y / ncb) * OB, c0 = (blockIdx.y % ncb) * CB, n = blockIdx.z;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < OB * 256; i += 256) {
+        const int o = i / 256, p = i % 256, y = ty0 + p / 16, x = tx0 + p % 16, oo = o0 + o;
+        dyt[o][p] = (oo < a.Cout && y < a.H && x < a.W) ? a.dy[(((size_t)n * a.Cout + oo) * a.H + y) * a.W + x] : 0.0f;
+    }
+    for (int i = tid; i < CB * LT * LT; i += 256) {
+        const int c = i / (LT * LT), r = i % (LT * LT), yy = r / LT, xx = r % LT;
+        const int gy = ty0 - P + yy, gx = tx0 - P + xx, cc = c0 + c;
+        float v = 0.0f;
+        if (cc < Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            const bool first = cc < a.C0;
+            const float* src = first ? a.x0 : a.x1;
+            const int Cs = first ? a.C0 : a.C1, cs = first ? cc : cc - a.C0;
+            v = src[(((size_t)n * Cs + cs) * a.Hs + (gy >> a.up)) * a.Ws + (gx >> a.up)];
+        }
+        xt[c][yy][xx] = v;
+    }
+    __syncthreads();
+    const int o = tid / CB, c = tid % CB;
+    float acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t] = 0.0f;
+    for (int p = 0; p < 256; ++p) {
+        const float g = dyt[o][p];
+        const int py = p / 16, px = p % 16;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) acc[t] = fmaf(g, xt[c][py + t / K][px + t % K], acc[t]);
+    }
+    if (o0 + o < a.Cout && c0 + c < Cin) {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) atomicAdd(&a.dw[((size_t)(o0 + o) * Cin + c0 + c) * KK + t], acc[t]);
+    }
+    if (a.db && c0 == 0 && o0 + o < a.Cout) {      // bias gradient: the 16 c-lanes of an output channel split the pixels
+        float s = 0.0f;
+        for (int p = c; p < 256; p += CB) s += dyt[o][p];
+        atomicAdd(&a.db[o0 + o], s);
+    }
+}
+
+// ---- BatchNorm (training) + LeakyReLU + Dropout -------------------------------------------------
+// per-channel double-precision sums over (n, HW): sums[c] += sum f1, sums[C + c] += sum f2
+template <int MODE>   // 0: f1 = v, f2 = v*v;  1: f1 = dz, f2 = dz * xhat
+__global__ __launch_bounds__(256) void bn_reduce_kernel(int n, int C, int HW, const float* v, const float* g, const float* gamma,
+                                                        const float* beta, float eps, const float* mean, const float* var,
+                                                        const uint8_t* mask, float drop_scale, double* sums) {
+    __shared__ double s1[256], s2[256];
+    const int c = blockIdx.x;
+    const long total = (long)n * HW;
+    double a1 = 0.0, a2 = 0.0;
+    float mu = 0.f, inv = 0.f, ga = 0.f, be = 0.f;
+    if (MODE == 1) { mu = mean[c]; inv = 1.0f / sqrtf(var[c] + eps); ga = gamma[c]; be = beta[c]; }
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        const size_t idx = ((size_t)(i / HW) * C + c) * HW + i % HW;
+        const float x = v[idx];
+        if (MODE == 0) { a1 += x; a2 += (double)x * x; }
+        else {
+            const float xh = (x - mu) * inv, z = ga * xh + be;
+            float dz = g[idx] * (z > 0.0f ? 1.0f : 0.2f);
+            if (mask) dz *= mask[idx] ? drop_scale : 0.0f;
+            a1 += dz; a2 += (double)dz * xh;
+        }
+    }
+    s1[threadIdx.x] = a1; s2[threadIdx.x] = a2;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) { s1[threadIdx.x] += s1[threadIdx.x + k]; s2[threadIdx.x] += s2[threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicAdd(&sums[c], s1[0]); atomicAdd(&sums[C + c], s2[0]); }
+}
+
+__global__ void bn_stats_finish_kernel(int C, double count, const double* sums, float momentum, float* mean, float* var,
+                                       float* running_mean, float* running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / count;
+    double vv = sums[C + c] / count - m * m;
+    if (vv < 0.0) vv = 0.0;
+    mean[c] = (float)m; var[c] = (float)vv;
+    if (running_mean) running_mean[c] = running_mean[c] * momentum + (float)m * (1.0f - momentum);
+    if (running_var) running_var[c] = running_var[c] * momentum + (float)vv * (1.0f - momentum);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(long total, int C, int HW, const float* v, const float* gamma, const float* beta,
+                                                       float eps, const float* mean, const float* var, const uint8_t* mask,
+                                                       float drop_scale, float* y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)((i / HW) % C);
+        const float xh = (v[i] - mean[c]) / sqrtf(var[c] + eps);
+        float o = lrelu02(gamma[c] * xh + beta[c]);
+        if (mask) o *= mask[i] ? drop_scale : 0.0f;
+        y[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long total, int C, int HW, double count, const float* v, const float* gamma,
+                                                           const float* beta, float eps, const float* mean, const float* var,
+                                                           const uint8_t* mask, float drop_scale, const double* sums, float* g) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)((i / HW) % C);
+        const float inv = 1.0f / sqrtf(var[c] + eps);
+        const float xh = (v[i] - mean[c]) * inv, z = gamma[c] * xh + beta[c];
+        float dz = g[i] * (z > 0.0f ? 1.0f : 0.2f);
+        if (mask) dz *= mask[i] ? drop_scale : 0.0f;
+        const float dbeta = (float)(sums[c] / count), dgamma = (float)(sums[C + c] / count);
+        g[i] = gamma[c] * inv * (dz - dbeta - xh * dgamma);
+    }
+}
+
+__global__ void bn_param_grad_kernel(int C, const double* sums, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] += (float)sums[c];
+    dgamma[c] += (float)sums[C + c];
+}
+
+// ---- loss ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_ce_kernel(int K, int HW, const float* logits, const int8_t* labels, float* loss,
+                                                         float* dlogits, float grad_scale) {
+    __shared__ float ssum[256];
+    const int n = blockIdx.y;
+    float my = 0.0f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        const int l = labels[(size_t)n * HW + p];
+        float m = -3.4e38f;
+        for (int o = 0; o < K; ++o) m = fmaxf(m, logits[((size_t)n * K + o) * HW + p]);
+        float se = 0.0f;
+        for (int o = 0; o < K; ++o) se += expf(logits[((size_t)n * K + o) * HW + p] - m);
+        const float w = l > -1 ? 1.0f : 0.0f;
+        const int lc = l < 0 ? 0 : (l >= K ? K - 1 : l);
+        for (int o = 0; o < K; ++o) {
+            const float sm = expf(logits[((size_t)n * K + o) * HW + p] - m) / se;
+            dlogits[((size_t)n * K + o) * HW + p] = (sm - (o == lc ? 1.0f : 0.0f)) * w * grad_scale / (float)HW;
+        }
+        my += w * ((m + logf(se)) - logits[((size_t)n * K + lc) * HW + p]);
+    }
+    ssum[threadIdx.x] = my;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) ssum[threadIdx.x] += ssum[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(&loss[n], ssum[0] / (float)HW);
+}
+
+// ---- small elementwise pieces -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(long total, int Hs, int Ws, const float* dy, float* dx, int accumulate) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % Ws), y = (int)((i / Ws) % Hs);
+        const long plane = i / ((long)Hs * Ws);
+        const float* s = dy + (plane * 2 * Hs + 2 * y) * 2 * Ws + 2 * x;
+        const float v = (s[0] + s[1]) + (s[2 * Ws] + s[2 * Ws + 1]);
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(long total, const float* a, const float* b, float* out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(long total, unsigned long long seed, unsigned stream_id, float keep, uint8_t* mask) {
+    const long quads = (total + 3) / 4;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
+        unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32), stream_id, 0x44524F50u /* "DROP" */};
+        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long i = 4 * q + j;
+            if (i < total) mask[i] = (((float)(c[j] >> 8) + 0.5f) * 5.9604644775390625e-8f) < keep ? 1 : 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(long total, float* w, const float* g, float* m, float* v, float lr_t, float b1,
+                                                   float b2, float eps, float rescale, float wd) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float gg = g[i] * rescale + wd * w[i];
+        const float mm = b1 * m[i] + (1.0f - b1) * gg;
+        const float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
+        m[i] = mm; v[i] = vv;
+        w[i] -= lr_t * mm / (sqrtf(vv) + eps);
+    }
+}
+
+// per-device scratch for the BatchNorm reductions (2 * 8192 doubles), zeroed on the caller's stream before use
+double* bn_scratch() {
+    static std::mutex mu;
+    static double* buf[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!buf[dev] && hipMalloc(reinterpret_cast<void**>(&buf[dev]), sizeof(double) * 2 * 8192) != hipSuccess) return nullptr;
+    return buf[dev];
+}
+
+inline int grid_for(long total) { long g = (total + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
+}  // namespace
+
+extern "C" {
+
+int gsa_train_conv(void* stream, int32_t n, const float* x0, int32_t C0, const float* x1, int32_t C1, int32_t Hs, int32_t Ws,
+                   int32_t up, const float* w, int32_t Cout, int32_t K, int32_t transposed, const float* bias, float* out0,
+                   int32_t Cout0, float* out1, int32_t accumulate) {
+    if (n <= 0 || !x0 || C0 <= 0 || C1 < 0 || (C1 > 0 && !x1) || Hs <= 0 || Ws <= 0 || (up != 0 && up != 1) || !w || Cout <= 0 ||
+        (K != 1 && K != 3) || !out0 || Cout0 <= 0 || Cout0 > Cout || (Cout0 < Cout && !out1))
+        return GSA_ERR_INVALID_;
+    ConvArgs a{x0, x1, C0, C1, Hs, Ws, up, Hs << up, Ws << up, w, Cout, transposed, bias, out0, Cout0, out1, accumulate};
+    const dim3 grid(((a.H + 15) / 16) * ((a.W + 15) / 16), (Cout + 15) / 16, n);
+    if (K == 3) hipLaunchKernelGGL(conv_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+int gsa_train_conv_wgrad(void* stream, int32_t n, const float* x0, int32_t C0, const float* x1, int32_t C1, int32_t Hs, int32_t Ws,
+                         int32_t up, const float* dy, int32_t Cout, int32_t K, float* dw, float* db) {
+    if (n <= 0 || !x0 || C0 <= 0 || C1 < 0 || (C1 > 0 && !x1) || Hs <= 0 || Ws <= 0 || (up != 0 && up != 1) || !dy || Cout <= 0 ||
+        (K != 1 && K != 3) || !dw)
+        return GSA_ERR_INVALID_;
+    WgradArgs a{x0, x1, C0, C1, Hs, Ws, up, Hs << up, Ws << up, dy, Cout, dw, db};
+    const int Cin = C0 + C1;
+    const dim3 grid(((a.H + 15) / 16) * ((a.W + 15) / 16), ((Cout + 15) / 16) * ((Cin + 15) / 16), n);
+    if (K == 3) hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+int gsa_train_bn_lrelu_fwd(void* stream, int32_t n, int32_t C, int32_t HW, const float* v, const float* gamma, const float* beta,
+                           float eps, float momentum, float* mean, float* var, float* running_mean, float* running_var,
+                           const uint8_t* mask, float drop_scale, float* y) {
+    if (n <= 0 || C <= 0 || C > 8192 || HW <= 0 || !v || !gamma || !beta || !mean || !var || !y) return GSA_ERR_INVALID_;
+    hipStream_t s = (hipStream_t)stream;
+    double* sums = bn_scratch();
+    if (!sums) return GSA_ERR_HIP_;
+    TRY_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s));
+    const long total = (long)n * HW;
+    const int chunks = (int)((total + 256 * 64 - 1) / (256 * 64));
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(C, chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks)), dim3(256), 0, s, n, C, HW, v,
+                       (const float*)nullptr, gamma, beta, eps, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, 1.0f, sums);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, C, (double)total, sums, momentum, mean, var,
+                       running_mean, running_var);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total * C)), dim3(256), 0, s, total * C, C, HW, v, gamma, beta, eps, mean, var, mask,
+                       drop_scale, y);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+int gsa_train_bn_lrelu_bwd(void* stream, int32_t n, int32_t C, int32_t HW, const float* v, const float* gamma, const float* beta,
+                           float eps, const float* mean, const float* var, const uint8_t* mask, float drop_scale, float* g,
+                           float* dgamma, float* dbeta) {
+    if (n <= 0 || C <= 0 || C > 8192 || HW <= 0 || !v || !gamma || !beta || !mean || !var || !g || !dgamma || !dbeta) return GSA_ERR_INVALID_;
+    hipStream_t s = (hipStream_t)stream;
+    double* sums = bn_scratch();
+    if (!sums) return GSA_ERR_HIP_;
+    TRY_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s));
+    const long total = (long)n * HW;
+    const int chunks = (int)((total + 256 * 64 - 1) / (256 * 64));
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(C, chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks)), dim3(256), 0, s, n, C, HW, v, (const float*)g,
+                       gamma, beta, eps, mean, var, mask, drop_scale, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total * C)), dim3(256), 0, s, total * C, C, HW, (double)total, v, gamma, beta, eps, mean,
+                       var, mask, drop_scale, (const double*)sums, g);
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, s, C, (const double*)sums, dgamma, dbeta);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+int gsa_train_softmax_ce(void* stream, int32_t n, int32_t classes, int32_t HW, const float* logits, const int8_t* labels, float* loss,
+                         float* dlogits, float grad_scale) {
+    if (n <= 0 || classes < 2 || classes > 64 || HW <= 0 || !logits || !labels || !loss || !dlogits) return GSA_ERR_INVALID_;
+    hipStream_t s = (hipStream_t)stream;
+    TRY_HIP(hipMemsetAsync(loss, 0, sizeof(float) * n, s));
+    const int gx = (HW + 255) / 256;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(gx > 1024 ? 1024 : gx, n), dim3(256), 0, s, classes, HW, logits, labels, loss, dlogits, grad_scale);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+int gsa_train_upsample2_bwd(void* stream, int32_t n, int32_t C, int32_t Hs, int32_t Ws, const float* dy_up, float* dx, int32_t accumulate) {
+    if (n <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || !dy_up || !dx) return GSA_ERR_INVALID_;
+    const long total = (long)n * C * Hs * Ws;
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, total, Hs, Ws, dy_up, dx, accumulate);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+int gsa_train_add(void* stream, int64_t count, const float* a, const float* b, float* out) {
+    if (count <= 0 || !a || !b || !out) return GSA_ERR_INVALID_;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, (long)count, a, b, out);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+int gsa_train_dropout_mask(void* stream, int64_t count, uint64_t seed, uint32_t stream_id, float keep_prob, uint8_t* mask) {
+    if (count <= 0 || !mask || !(keep_prob > 0.0f && keep_prob <= 1.0f)) return GSA_ERR_INVALID_;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((count + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (long)count,
+                       (unsigned long long)seed, stream_id, keep_prob, mask);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+int gsa_train_adam(void* stream, int64_t count, float* w, const float* g, float* m, float* v, float lr_t, float beta1, float beta2,
+                   float eps, float rescale, float wd) {
+    if (count <= 0 || !w || !g || !m || !v) return GSA_ERR_INVALID_;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, (long)count, w, g, m, v, lr_t, beta1, beta2, eps,
+                       rescale, wd);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+}  // extern "C"
