@@ -3,8 +3,8 @@
     solver = SegSolver(max_res_log2, path_to_data, checkpoints_dir, gpu_ids, keep_weights=False)
     if solver.is_trained: mask = solver.predict(features)    # (N,H,W,1) float32 in {0..K-1}
 
-``evaluate`` (pixAcc / mIoU / weighted softmax-CE over annotated samples) runs on
-the device too.  Training (``fit``) stays outside the `generate` hot path and raises NotImplementedError.
+``evaluate`` (pixAcc / mIoU / weighted softmax-CE over annotated samples) and ``fit``
+(section 8f-3: the decoder's training loop, ``trainer.DecoderTrainer``) run on the device too.
 """
 import os
 
@@ -76,8 +76,47 @@ class SegSolver:
         torch.cuda.synchronize()
         return mask.cpu().numpy().astype(np.float32)
 
-    def fit(self, *args, **kwargs):
-        raise NotImplementedError("decoder training is outside the generate hot path (SURVEY.md section 8f)")
+    # -- training ---------------------------------------------------------
+    def fit(self, epoch_end_callback=None, epochs=None, seed=None, log=None):
+        """Train the decoder on the annotated samples of ``path_to_data`` (``feat_*.pickle`` + ``mask_*.png``) as
+        reference ``fit`` (:351-465): batch size 1, ``train_epochs`` epochs (24) of shuffled samples, Adam(1e-4),
+        weighted softmax-CE, then ``save()``.  Every operator runs on the MI355X (``trainer.DecoderTrainer``).
+        ``keep_weights=False`` starts from a fresh Xavier initialisation as the reference does.  Returns the mean
+        loss of each epoch."""
+        import random
+        from . import annotation_io
+        from .trainer import DecoderTrainer
+        names = sorted(f for f in os.listdir(self.path_to_data) if f.endswith(".pickle") and "feat" in f)
+        if not names:
+            raise ValueError("number of training samples should be > 0")          # reference :139-141
+        seed = 1 if seed is None else seed                                          # reference cfg['seed'] = 1
+        if self.keep_weights and getattr(self.net, "_tensors", None) is not None:
+            start = self.net._tensors
+        else:
+            start = _weights.initial_decoder_params(self.cfg, seed)
+        tr = DecoderTrainer(self.cfg, start, device=self.ctx[0], lr=1e-4, wd=0.0, seed=seed)     # reference cfg: adam, base_lr 1e-4, wd 0
+        epochs = 24 if epochs is None else epochs                                                # reference cfg['train_epochs']
+        rng = random.Random(seed)
+        history = []
+        for epoch in range(epochs):
+            order = list(names)
+            rng.shuffle(order)
+            total = 0.0
+            for fname in order:
+                image_id = int(os.path.splitext(fname)[0].split("_")[-1])
+                mask, _img, feats = annotation_io.load_sample(self.path_to_data, image_id)
+                if mask is None:
+                    raise ValueError("no mask for %s" % fname)
+                total += tr.step(feats, mask[None])
+            history.append(total / len(order))
+            if log is not None:
+                log("Epoch[%d] Train-total-loss=%f" % (epoch + 1, history[-1]))
+            if epoch_end_callback is not None:
+                epoch_end_callback()
+        self.net.load_parameters(tr.state_dict())
+        self.is_trained = True
+        self.save()
+        return history
 
     # -- evaluation (SURVEY.md section 8f-4) ------------------------------------------------------
     def evaluate_batch(self, features, labels, metric=None):

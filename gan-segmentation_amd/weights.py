@@ -227,6 +227,25 @@ def decoder_param_shapes(cfg):
     return shapes
 
 
+def initial_decoder_params(cfg, seed=1):
+    """Fresh decoder for training, as reference ``init_net`` (seg_solver.py:36-46): conv weights
+    ``mx.init.Xavier(factor_type='in', magnitude=2.34)`` = U(-s, s) with s = sqrt(2.34/fan_in), biases 0,
+    BatchNorm gamma 1 / beta 0 / running_mean 0 / running_var 1 (gluon defaults)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for name, shape in decoder_param_shapes(cfg).items():
+        if name.endswith(".weight"):
+            fan_in = shape[1] * shape[2] * shape[3]
+            s = math.sqrt(2.34 / fan_in)
+            v = rng.uniform(-s, s, size=shape)
+        elif name.endswith((".gamma", ".running_var")):
+            v = np.ones(shape)
+        else:
+            v = np.zeros(shape)
+        out[name] = np.ascontiguousarray(v, dtype=np.float32)
+    return out
+
+
 def synthetic_decoder_params(cfg, seed=3):
     """Random decoder weights: Xavier(in, 2.34) convs (reference seg_solver.py:38),
     non-trivial BatchNorm statistics."""

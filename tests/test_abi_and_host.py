@@ -34,6 +34,19 @@ def test_header_symbols_are_exported(hip_library):
     assert b"gfx950" in api.version()
 
 
+def test_training_header_symbols_are_exported(hip_library):
+    """include/gsa_train.h (decoder-training operators) <-> library exports <-> the ctypes table of train_ops."""
+    with open(os.path.join(ROOT, "include", "gsa_train.h")) as f:
+        header = f.read()
+    declared = set(re.findall(r"\bint\s+(gsa_train_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) == 9
+    lib = ctypes.CDLL(hip_library)
+    for name in declared:
+        assert hasattr(lib, name), "%s declared in gsa_train.h but not exported" % name
+    from gan_segmentation_amd import train_ops
+    assert set(train_ops._api().keys()) == declared
+
+
 def test_product_path_fails_loudly_without_gpu(hip_library):
     import torch
     if torch.cuda.is_available():

@@ -1,0 +1,113 @@
+"""One and two optimisation steps of the on-device decoder trainer against the torch-autograd restatement
+(oracle/ref_train.py) with the SAME dropout masks."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_training_steps_match_autograd():
+    import torch
+    from gan_segmentation_amd import weights as W
+    from gan_segmentation_amd.trainer import DecoderTrainer
+    from oracle import ref_train
+    mr = 6                                                    # 64x64 output, 5 levels: both shortcut kinds, concat, final conv
+    gcfg = W.reduced_generator_config(mr)
+    chans = W.generator_channels(gcfg)
+    dcfg = W.decoder_config(mr, in_channels=chans)
+    dp = W.synthetic_decoder_params(dcfg, seed=4)
+    rng = np.random.default_rng(0)
+    n = 2
+    feats = [rng.standard_normal((n, c, 4 << i, 4 << i)).astype(np.float32) for i, c in enumerate(chans)]
+    R = 4 << (len(chans) - 1)
+    labels = rng.integers(0, 2, (n, R, R)).astype(np.int64)
+    labels[rng.random((n, R, R)) < 0.2] = -1
+    tr = DecoderTrainer(dcfg, dp, lr=1e-2, seed=5)            # a large step so that the update is well above rounding
+    params = {k: v.copy() for k, v in dp.items()}
+    m = {k: np.zeros_like(v) for k, v in dp.items()}
+    v_ = {k: np.zeros_like(v) for k, v in dp.items()}
+    for step in (1, 2):
+        masks = tr.dropout_masks([(n, dcfg["features"][i], 4 << i, 4 << i) for i in range(len(chans))])
+        masks_np = [mk.cpu().numpy() for mk in masks]
+        loss = tr.step(feats, labels, masks=masks)
+        per_sample, params, m, v_, grads = ref_train.train_step(dcfg, params, feats, labels, masks_np, step, m, v_, lr=1e-2)
+        assert abs(loss - per_sample.mean()) <= 2e-5 * max(1.0, per_sample.mean())
+        got = tr.state_dict()
+        for k in params:
+            a, b = got[k], params[k]
+            if k.endswith(("running_mean", "running_var")):
+                tol = 1e-4 * max(1.0, np.abs(b).max())
+            elif k.endswith(".bias") and ("cvt_block" in k or "base_layers" in k):
+                continue     # a bias in front of BatchNorm has an exactly-zero gradient: Adam turns its rounding noise into +-lr steps
+            else:
+                # Adam steps are ~lr whatever the gradient's scale, so an element whose gradient is at rounding level
+                # moves by +-lr with a rounding-dependent sign: compare in the bulk, against the step size
+                d = np.abs(a - b)
+                lr_step = 1e-2 * step
+                outliers = int(np.sum(d > 0.1 * lr_step))
+                assert np.median(d) <= 0.01 * lr_step and outliers <= max(2, 0.01 * d.size), \
+                    "%s after step %d: median %.3e, %d of %d elements off by > 0.1 lr" % (k, step, np.median(d), outliers, d.size)
+                continue
+            assert np.abs(a - b).max() <= tol, "%s after step %d: %.3e vs tol %.3e" % (k, step, np.abs(a - b).max(), tol)
+    assert not np.array_equal(tr.state_dict()["cvt_block_0.0.weight"], dp["cvt_block_0.0.weight"])
+
+
+def test_gradients_match_autograd_directly():
+    """The raw gradients (before Adam's normalisation hides their scale)."""
+    import torch
+    from gan_segmentation_amd import weights as W
+    from gan_segmentation_amd.trainer import DecoderTrainer
+    from oracle import ref_train
+    mr = 5
+    gcfg = W.reduced_generator_config(mr)
+    chans = W.generator_channels(gcfg)
+    dcfg = W.decoder_config(mr, in_channels=chans)
+    dp = W.synthetic_decoder_params(dcfg, seed=6)
+    rng = np.random.default_rng(1)
+    feats = [rng.standard_normal((1, c, 4 << i, 4 << i)).astype(np.float32) for i, c in enumerate(chans)]
+    R = 4 << (len(chans) - 1)
+    labels = rng.integers(-1, 2, (1, R, R)).astype(np.int64)
+    tr = DecoderTrainer(dcfg, dp, lr=0.0, seed=2)             # lr 0: parameters stay, gradients remain readable
+    masks = tr.dropout_masks([(1, dcfg["features"][i], 4 << i, 4 << i) for i in range(len(chans))])
+    tr.step(feats, labels, masks=masks)
+    zeros = {k: np.zeros_like(v) for k, v in dp.items()}
+    _ps, _p, _m, _v, grads = ref_train.train_step(dcfg, dp, feats, labels, [mk.cpu().numpy() for mk in masks], 1, zeros, zeros, lr=0.0)
+    for k, gref in grads.items():
+        got = tr.g[k].cpu().numpy()
+        scale = max(1e-6, np.abs(gref).max())
+        assert np.abs(got - gref).max() <= 2e-3 * scale + 1e-6, "%s: %.3e of %.3e" % (k, np.abs(got - gref).max(), scale)
+
+
+def test_solver_fit_learns_and_saves(tmp_path):
+    """SegSolver.fit over annotator sample files: the loss falls, the checkpoint reloads, evaluate improves."""
+    from PIL import Image
+    from gan_segmentation_amd import annotation_io, weights as W
+    from gan_segmentation_amd.seg_solver import SegSolver
+    mr = 6
+    gcfg = W.reduced_generator_config(mr)
+    chans = W.generator_channels(gcfg)
+    rng = np.random.default_rng(3)
+    R = 4 << (len(chans) - 1)
+    data = tmp_path / "data"
+    yy, xx = np.mgrid[0:R, 0:R]
+    for i in range(4):
+        feats = [rng.standard_normal((c, 4 << l, 4 << l)).astype(np.float32) for l, c in enumerate(chans)]
+        inside = (yy - R / 2 - 3 * i) ** 2 + (xx - R / 2 + 2 * i) ** 2 < (R / 3.5) ** 2        # a disc to segment ...
+        feats[-1][0] = np.where(inside, 1.5, -1.5) + 0.3 * feats[-1][0]                          # ... visible in the finest feature
+        img = np.zeros((R, R, 3), np.uint8)
+        annotation_io.export_sample(str(data), i, img, feats)
+        m = np.where(inside, 230, 128).astype(np.uint8)
+        m[:2] = 20                                                                               # a strip of ignored pixels
+        Image.fromarray(m, "L").save(str(data / ("mask_%06d.png" % i)))
+    ckpt = tmp_path / "checkpoints"
+    solver = SegSolver(mr, str(data), str(ckpt), gpu_ids=[0], keep_weights=False, in_channels=chans)
+    assert not solver.is_trained
+    lines = []
+    history = solver.fit(epochs=12, log=lines.append)
+    assert len(history) == 12 and len(lines) == 12
+    assert history[-1] < 0.5 * history[0], history
+    assert solver.is_trained and (ckpt / "checkpoint_last.params").exists()
+    result = dict(solver.evaluate(str(data)))
+    assert result["accuracy"] > 0.9 and result["mean-iou"] > 0.75, result
+    again = SegSolver(mr, str(data), str(ckpt), gpu_ids=[0], in_channels=chans)                 # the saved checkpoint loads
+    assert again.is_trained and dict(again.evaluate(str(data)))["accuracy"] == result["accuracy"]
