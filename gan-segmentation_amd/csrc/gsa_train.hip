@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 // ---- weight / bias gradient ---------------------------------------------------------------------
 struct WgradArgs {
     const float* x0; const float* x1; int C0, C1, Hs, Ws, up, H, W;
-    const float* dy; int Cout; float* dw; float* db;
+    const float* dy; int Cout; float* dw; float* db; int n;
 };
 
 template <int K>
@@ -104,47 +104,51 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     constexpr int P = K / 2, LT = 16 + 2 * P, KK = K * K, OB = 16, CB = 16;
     __shared__ float dyt[OB][256];
     __shared__ float xt[CB][LT][LT + 1];
-    const int tiles_x = (a.W + 15) / 16;
-    const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+    const int tiles_x = (a.W + 15) / 16, tiles = tiles_x * ((a.H + 15) / 16);
     const int Cin = a.C0 + a.C1, ncb = (Cin + CB - 1) / CB;
-    const int o0 = (blockIdx.y / ncb) * OB, c0 = (blockIdx.y % ncb) * CB, n = blockIdx.z;
+    const int o0 = (blockIdx.y / ncb) * OB, c0 = (blockIdx.y % ncb) * CB;
     const int tid = threadIdx.x;
-    for (int i = tid; i < OB * 256; i += 256) {
-        const int o = i / 256, p = i % 256, y = ty0 + p / 16, x = tx0 + p % 16, oo = o0 + o;
-        dyt[o][p] = (oo < a.Cout && y < a.H && x < a.W) ? a.dy[(((size_t)n * a.Cout + oo) * a.H + y) * a.W + x] : 0.0f;
-    }
-    for (int i = tid; i < CB * LT * LT; i += 256) {
-        const int c = i / (LT * LT), r = i % (LT * LT), yy = r / LT, xx = r % LT;
-        const int gy = ty0 - P + yy, gx = tx0 - P + xx, cc = c0 + c;
-        float v = 0.0f;
-        if (cc < Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-            const bool first = cc < a.C0;
-            const float* src = first ? a.x0 : a.x1;
-            const int Cs = first ? a.C0 : a.C1, cs = first ? cc : cc - a.C0;
-            v = src[(((size_t)n * Cs + cs) * a.Hs + (gy >> a.up)) * a.Ws + (gx >> a.up)];
-        }
-        xt[c][yy][xx] = v;
-    }
-    __syncthreads();
     const int o = tid / CB, c = tid % CB;
-    float acc[KK];
+    float acc[KK], bsum = 0.0f;
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[t] = 0.0f;
-    for (int p = 0; p < 256; ++p) {
-        const float g = dyt[o][p];
-        const int py = p / 16, px = p % 16;
+    // a block walks many (sample, tile) pairs and keeps its 16x16xKK partial sums in registers: one atomic per
+    // weight and block at the end (one block per tile made 4096 blocks contend on the same 2304 addresses)
+    for (int work = blockIdx.x; work < tiles * a.n; work += gridDim.x) {
+        const int n = work / tiles, tile = work % tiles;
+        const int ty0 = (tile / tiles_x) * 16, tx0 = (tile % tiles_x) * 16;
+        __syncthreads();
+        for (int i = tid; i < OB * 256; i += 256) {
+            const int oo_l = i / 256, p = i % 256, y = ty0 + p / 16, x = tx0 + p % 16, oo = o0 + oo_l;
+            dyt[oo_l][p] = (oo < a.Cout && y < a.H && x < a.W) ? a.dy[(((size_t)n * a.Cout + oo) * a.H + y) * a.W + x] : 0.0f;
+        }
+        for (int i = tid; i < CB * LT * LT; i += 256) {
+            const int cl = i / (LT * LT), r = i % (LT * LT), yy = r / LT, xx = r % LT;
+            const int gy = ty0 - P + yy, gx = tx0 - P + xx, cc = c0 + cl;
+            float v = 0.0f;
+            if (cc < Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const bool first = cc < a.C0;
+                const float* src = first ? a.x0 : a.x1;
+                const int Cs = first ? a.C0 : a.C1, cs = first ? cc : cc - a.C0;
+                v = src[(((size_t)n * Cs + cs) * a.Hs + (gy >> a.up)) * a.Ws + (gx >> a.up)];
+            }
+            xt[cl][yy][xx] = v;
+        }
+        __syncthreads();
+        for (int p = 0; p < 256; ++p) {
+            const float g = dyt[o][p];
+            const int py = p / 16, px = p % 16;
 #pragma unroll
-        for (int t = 0; t < KK; ++t) acc[t] = fmaf(g, xt[c][py + t / K][px + t % K], acc[t]);
+            for (int t = 0; t < KK; ++t) acc[t] = fmaf(g, xt[c][py + t / K][px + t % K], acc[t]);
+        }
+        if (a.db && c0 == 0)      // bias gradient: the 16 c-lanes of an output channel split the pixels
+            for (int p = c; p < 256; p += CB) bsum += dyt[o][p];
     }
     if (o0 + o < a.Cout && c0 + c < Cin) {
 #pragma unroll
         for (int t = 0; t < KK; ++t) atomicAdd(&a.dw[((size_t)(o0 + o) * Cin + c0 + c) * KK + t], acc[t]);
     }
-    if (a.db && c0 == 0 && o0 + o < a.Cout) {      // bias gradient: the 16 c-lanes of an output channel split the pixels
-        float s = 0.0f;
-        for (int p = c; p < 256; p += CB) s += dyt[o][p];
-        atomicAdd(&a.db[o0 + o], s);
-    }
+    if (a.db && c0 == 0 && o0 + o < a.Cout) atomicAdd(&a.db[o0 + o], bsum);
 }
 
 // ---- BatchNorm (training) + LeakyReLU + Dropout -------------------------------------------------
@@ -339,9 +343,12 @@ int gsa_train_conv_wgrad(void* stream, int32_t n, const float* x0, int32_t C0, c
     if (n <= 0 || !x0 || C0 <= 0 || C1 < 0 || (C1 > 0 && !x1) || Hs <= 0 || Ws <= 0 || (up != 0 && up != 1) || !dy || Cout <= 0 ||
         (K != 1 && K != 3) || !dw)
         return GSA_ERR_INVALID_;
-    WgradArgs a{x0, x1, C0, C1, Hs, Ws, up, Hs << up, Ws << up, dy, Cout, dw, db};
+    WgradArgs a{x0, x1, C0, C1, Hs, Ws, up, Hs << up, Ws << up, dy, Cout, dw, db, n};
     const int Cin = C0 + C1;
-    const dim3 grid(((a.H + 15) / 16) * ((a.W + 15) / 16), ((Cout + 15) / 16) * ((Cin + 15) / 16), n);
+    const int pairs = ((Cout + 15) / 16) * ((Cin + 15) / 16), work = ((a.H + 15) / 16) * ((a.W + 15) / 16) * n;
+    int gx = (1024 + pairs - 1) / pairs;          // ~1024 blocks in all: enough to fill the chip, few atomics per address
+    gx = gx < 1 ? 1 : (gx > work ? work : gx);
+    const dim3 grid(gx, pairs, 1);
     if (K == 3) hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
     TRY_HIP(hipGetLastError());
