@@ -135,12 +135,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             xt[cl][yy][xx] = v;
         }
         __syncthreads();
-        for (int p = 0; p < 256; ++p) {
-            const float g = dyt[o][p];
-            const int py = p / 16, px = p % 16;
+        // four consecutive pixels at a time: a row segment of 4+K-1 inputs serves all K horizontal taps (0.6 LDS
+        // reads per FMA instead of 1.1)
+        for (int py = 0; py < 16; ++py)
 #pragma unroll
-            for (int t = 0; t < KK; ++t) acc[t] = fmaf(g, xt[c][py + t / K][px + t % K], acc[t]);
-        }
+            for (int q = 0; q < 4; ++q) {
+                float g[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = dyt[o][py * 16 + q * 4 + j];
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    float xr[4 + K - 1];
+#pragma unroll
+                    for (int j = 0; j < 4 + K - 1; ++j) xr[j] = xt[c][py + ky][q * 4 + j];
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ky * K + kx] = fmaf(g[j], xr[j + kx], acc[ky * K + kx]);
+                }
+            }
         if (a.db && c0 == 0)      // bias gradient: the 16 c-lanes of an output channel split the pixels
             for (int p = c; p < 256; p += CB) bsum += dyt[o][p];
     }

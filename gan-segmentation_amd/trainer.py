@@ -145,10 +145,18 @@ class DecoderTrainer:
             gv = self._bn_bwd(cv + ".1", rec["cv_raw"], rec["cv_stats"], dcvt, masks[i])
             ops.conv_wgrad(feats[i], None, gv, 3, g[cv + ".0.weight"], g[cv + ".0.bias"])
 
+        # ---- data parallel (one process per GPU): sum the gradients over the ranks with RCCL -- the reference's
+        # kvstore 'nccl' (seg_solver.py:55); BatchNorm statistics stay per rank (use_sync_bn=False, :122)
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size()
+            if world > 1:
+                for name in g:
+                    torch.distributed.all_reduce(g[name])
         # ---- Adam (mx.optimizer.Adam; trainer.step(batch_size) -> rescale_grad = 1/batch)
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         for name in g:
-            ops.adam(p[name], g[name], self.m[name], self.v[name], lr_t, self.b1, self.b2, self.eps, rescale=1.0 / n, wd=self.wd)
+            ops.adam(p[name], g[name], self.m[name], self.v[name], lr_t, self.b1, self.b2, self.eps, rescale=1.0 / (n * world), wd=self.wd)
         return float(loss.cpu().numpy().mean())
 
     def _identity_up_add(self, x, y):
