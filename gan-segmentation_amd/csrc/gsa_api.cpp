@@ -117,6 +117,7 @@ struct gsa_ctx {
     hipEvent_t ev_level[kMaxLevels] = {nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int bf16 = 0;                 // gsa_set_precision: 1 = bf16 MFMA operands (fixed once weights are committed)
+    int dbg = 0;                  // GSA_DBG, read once at gsa_create (only the diagnostic build looks at it)
     int side_levels = kMaxLevels; // decoder levels 0..side_levels-1 (all but the last) go to the side stream (GSA_SIDE_LEVELS)
 
     // profiling
@@ -460,6 +461,7 @@ int gsa_create(int device, gsa_ctx** out) {
         return rc;
     }
     if (const char* v = getenv("GSA_SIDE_LEVELS")) c->side_levels = atoi(v);
+    if (const char* v = getenv("GSA_DBG")) c->dbg = atoi(v);
     *out = c;
     return GSA_OK;
 }
@@ -850,7 +852,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 if (!B.has_conv1) {
                     pp.src = c->constant; pp.src_per_sample = 0; pp.blur = nullptr;
                 } else {
-                    ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0; cp.bf16 = c->bf16;
+                    ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
                     cp.src0 = c->x2[l - 1]; cp.aff0 = c->aff2[l - 1]; cp.C0 = Cin;
                     cp.Hs = R / 2; cp.Ws = R / 2; cp.H = R; cp.W = R;
                     cp.wpk = B.w1; cp.Cout = C; cp.out = c->t_raw;
@@ -874,7 +876,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 HIP_TRY(launch_post(pp, n, s));
                 prow = post_prow(R, R, C);
             } else {
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0; cp.bf16 = c->bf16;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
                 cp.src0 = c->x1; cp.aff0 = c->aff1; cp.C0 = C;
                 cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
                 cp.wpk = B.w2; cp.Cout = C; cp.out = c->x2[l];
@@ -924,7 +926,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
         const double px = N * R * R;
         if (wait_levels) HIP_TRY(hipStreamWaitEvent(s, c->ev_level[i], 0));   // generator feature i is ready
         {   // cvt_block: conv3x3+bias -> BN -> LeakyReLU (Dropout is identity at inference)
-            ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0; cp.bf16 = c->bf16;
+            ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
             cp.src0 = fsrc[i]; cp.aff0 = faff ? faff[i] : nullptr; cp.C0 = d.I;
             cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
             cp.wpk = d.cvt_w; cp.Cout = d.F; cp.out = c->cvt[i];
@@ -937,7 +939,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             const int R2 = 2 * R;
             const double px2 = 4 * px;
             {   // ResBlock conv a (+ fused 1x1 shortcut) on nearest-x2(concat(prev, cvt))
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0; cp.bf16 = c->bf16;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
                 if (i > 0) { cp.src0 = c->prev[i - 1]; cp.C0 = d.F; cp.src1 = c->cvt[i]; cp.C1 = d.F; }
                 else { cp.src0 = c->cvt[i]; cp.C0 = d.F; }
                 cp.Hs = R; cp.Ws = R; cp.up = 1; cp.H = R2; cp.W = R2;
@@ -959,7 +961,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 }
             }
             {   // ResBlock conv b, + shortcut
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = getenv("GSA_DBG") ? atoi(getenv("GSA_DBG")) : 0; cp.bf16 = c->bf16;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
                 cp.src0 = c->ya[i]; cp.C0 = d.cs;
                 cp.Hs = R2; cp.Ws = R2; cp.H = R2; cp.W = R2;
                 cp.wpk = d.b_w; cp.Cout = d.cs; cp.out = c->prev[i];
