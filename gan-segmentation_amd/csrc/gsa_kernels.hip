@@ -1550,31 +1550,34 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[r][j] = 0.0f;
+            // all 18 loads are unconditional (clamped coordinates) and issued before the first use; taps outside the
+            // image are zeroed values: fmaf(0, w, b) == b bit for bit (b is never -0), i.e. the same as skipping them
+            float4 row[3][6];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int yy = y + ky - 1;
-                if (yy < 0 || yy >= p.H) continue;
-                float4 row[6];
+                const bool vy = yy >= 0 && yy < p.H;
+                const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     const int xx = x0 - 1 + k;
-                    row[k] = (xx >= 0 && xx < p.W)
-                                 ? *reinterpret_cast<const float4*>(src + ((size_t)yy * p.W + xx) * p.C + c)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+                    row[ky][k] = *reinterpret_cast<const float4*>(src + ((size_t)yc * p.W + xc) * p.C + c);
+                    if (!(vy && xx >= 0 && xx < p.W)) row[ky][k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int xx = x0 + r + kx - 1;
-                        if (xx < 0 || xx >= p.W) continue;   // skipped taps == +0
-                        const float4 t = row[r + kx];
+                        const float4 t = row[ky][r + kx];
                         v[r][0] = fmaf(t.x, wk[0][ky * 3 + kx], v[r][0]);
                         v[r][1] = fmaf(t.y, wk[1][ky * 3 + kx], v[r][1]);
                         v[r][2] = fmaf(t.z, wk[2][ky * 3 + kx], v[r][2]);
                         v[r][3] = fmaf(t.w, wk[3][ky * 3 + kx], v[r][3]);
                     }
-            }
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
