@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: bf16-MFMA mode of the HIP path against the C oracle in bf16 mode and against the fp32 path
+"""Diagnostic script (test infrastructure: it drives the oracle; run as `python tests/bf16_report.py [gan] [batch]`):
+bf16-MFMA mode of the HIP path against the C oracle in bf16 mode and against the fp32 path
 (reduced 128^2 model by default, `cars`/`ffhq`/`bedrooms` for the full sizes)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
