@@ -1772,16 +1772,24 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const fl
 // ------------------------------------------------------------------------------------------
 // toRGB (1x1 conv + bias) and the uint8 image of _transform_gan_back.
 // One thread per pixel reading its own channels: right for C <= 16 (one 64-byte line per pixel).
+template <int CT>      // CT = 16: the channel count is known, all four 16-byte loads of a pixel are issued up front
 __global__ __launch_bounds__(256) void torgb_direct_kernel(const float* x, const Aff* aff, const float* w, const float* b,
-                                                    float* rgb, uint8_t* img, int HW, int C, int nc) {
+                                                    float* rgb, uint8_t* img, int HW, int Crt, int nc) {
+    const int C = CT > 0 ? CT : Crt;
     const int n = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= HW) return;
     const float* px = x + ((size_t)n * HW + pix) * C;
     const Aff* a = aff + (size_t)n * C;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 pre[CT > 0 ? CT / 4 : 1];
+    if (CT > 0) {
+#pragma unroll
+        for (int k = 0; k < CT / 4; ++k) pre[k] = *reinterpret_cast<const float4*>(px + 4 * k);
+    }
+#pragma unroll
     for (int c = 0; c < C; c += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(px + c);
+        const float4 v = CT > 0 ? pre[c / 4] : *reinterpret_cast<const float4*>(px + c);
         const float f[4] = {fmaf(v.x - a[c].mean, a[c].A, a[c].B), fmaf(v.y - a[c + 1].mean, a[c + 1].A, a[c + 1].B),
                             fmaf(v.z - a[c + 2].mean, a[c + 2].A, a[c + 2].B), fmaf(v.w - a[c + 3].mean, a[c + 3].A, a[c + 3].B)};
 #pragma unroll
@@ -1923,28 +1931,42 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* src0, int 
 #pragma unroll
     for (int o = 0; o < NCLS; ++o) acc[o] = 0.0f;
     const int nblk0 = C0 >> 4, nblk = (C0 + C1) >> 4;
-    for (int cb = 0; cb < nblk; ++cb) {
+    // register prefetch: the 16-channel block cb+1 is loaded (unconditional, clamped; zero padding by select) while
+    // block cb is multiplied out of LDS
+    float4 pre[2][4];
+    auto load_block = [&](int cb) {
         const bool first = cb < nblk0;
         const float* src = first ? src0 : src1;
         const int Cs = first ? C0 : C1;
         const int coff = (first ? cb : cb - nblk0) * 16;
-        for (int idx = tid; idx < 18 * LW; idx += 256) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = min(tid + it * 256, 18 * LW - 1);
             const int sy = idx / LW, sx = idx % LW;
             const int gy = y0 - 1 + sy, gx = x0 - 1 + sx;
-            float4 v[4];
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const float4* ptr = reinterpret_cast<const float4*>(src + ((size_t)(n * H + gy) * W + gx) * Cs + coff);
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            const float4* ptr = reinterpret_cast<const float4*>(src + ((size_t)(n * H + cy) * W + cx) * Cs + coff);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = ptr[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < 4; ++k) {
+                pre[it][k] = ptr[k];
+                if (!inside) pre[it][k] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            float4* dst = reinterpret_cast<float4*>(smem + sy * RS + sx * CP);
+        }
+    };
+    load_block(0);
+    for (int cb = 0; cb < nblk; ++cb) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dst[k] = v[k];
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < 18 * LW) {
+                float4* dst = reinterpret_cast<float4*>(smem + (idx / LW) * RS + (idx % LW) * CP);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[k] = pre[it][k];
+            }
         }
         __syncthreads();
+        if (cb + 1 < nblk) load_block(cb + 1);
         const float* wb = wpk + (size_t)cb * 9 * 16 * NCLS;   // [tap][c][NCLS]
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -2433,7 +2455,8 @@ hipError_t launch_torgb(const float* x, const Aff* aff, const float* w, const fl
                         int n, int H, int W, int C, int nc, hipStream_t s) {
     if (nc > 4 || C % 4) return hipErrorInvalidValue;
     const int HW = H * W;
-    if (C <= 16) hipLaunchKernelGGL(torgb_direct_kernel, dim3((HW + 255) / 256, n), dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc);
+    if (C == 16) hipLaunchKernelGGL(torgb_direct_kernel<16>, dim3((HW + 255) / 256, n), dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc);
+    else if (C < 16) hipLaunchKernelGGL(torgb_direct_kernel<0>, dim3((HW + 255) / 256, n), dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc);
     else hipLaunchKernelGGL(torgb_kernel, dim3((HW + 255) / 256, n), dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc);
     return hipGetLastError();
 }
