@@ -1257,8 +1257,13 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 // MFMAs of item i -- the structure of conv3x3_mfma's double-buffered form.  Arithmetic order per output is
 // unchanged (bit-identical results).
 // KB = 16-channel blocks per item (2 when the block count is even: half as many workgroup barriers per MFMA).
-template <int NT, int EPI, bool SC, bool BF, int KB>
+// WST = the panel does not fit: weights are STREAMED through a two-block LDS ring shared by both halves (all 512
+// threads stage block it+1 while block it is multiplied; both halves are at the same channel block in every
+// iteration by construction), and blockIdx.y selects the output-channel group.  A weight block is then read once
+// per two tiles instead of once per tile.
+template <int NT, int EPI, bool SC, bool BF, int KB, bool WST>
 __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
+    static_assert(!WST || KB == 1, "streamed weights: one channel block per item");
     constexpr int PX = BF ? 8 : 16, TS = BF ? 128 : 256, KQ = BF ? 2 : 4;
     constexpr int LH = 10, LW = 10, RS = LW * PX + (BF ? 4 : 8);
     constexpr int SEG = 16 * TS, NB4 = NT * SEG / 4, BIT = (NB4 + 511) / 512;
@@ -1270,10 +1275,12 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     // The workgroup is two halves of 4 waves (one CU holds one workgroup, every SIMD one wave of each half): each
     // half walks its own tiles through its own double-buffered activation image, both read the ONE weight panel.
     const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
-    float* sW = smem;                              // [nblk][q][tap16][ci][16][cg]
-    float* sS = sW + nblk * NT * SEG;              // SC: [nblk][q][ci][16][cg]
-    float* sA = sS + (SC ? nblk * NT * TS : 0) + half * (2 * AB);            // per half [2][KB][LH*RS]
-    f32x4* sAff = reinterpret_cast<f32x4*>(sS + (SC ? nblk * NT * TS : 0) + 4 * AB) + half * (2 * KB * 16);   // per half [2][KB][16]
+    const int wblk = WST ? 2 : nblk;               // weight blocks held in LDS
+    const int g = WST ? (int)blockIdx.y : 0;       // output-channel group of this workgroup
+    float* sW = smem;                              // [wblk][q][tap16][ci][16][cg]
+    float* sS = sW + wblk * NT * SEG;              // SC: [wblk][q][ci][16][cg]
+    float* sA = sS + (SC ? wblk * NT * TS : 0) + half * (2 * AB);            // per half [2][KB][LH*RS]
+    f32x4* sAff = reinterpret_cast<f32x4*>(sS + (SC ? wblk * NT * TS : 0) + 4 * AB) + half * (2 * KB * 16);   // per half [2][KB][16]
     const int tid = threadIdx.x & 255, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int py = wave >> 1, px = wave & 1;
@@ -1323,34 +1330,44 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
         for (int nt = 0; nt < NT; ++nt) accs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // ---- the weight panel (and the shortcut's) -> LDS, once
-    for (int cbk = 0; cbk < nblk; ++cbk) {
-        f32x4 rb[BIT];
+    // ---- weights: the whole panel (and the shortcut's) -> LDS once, or (WST) block 0 now and block 1 into registers
+    f32x4 rbw[BIT], rsw[SC ? SIT : 1];
+    auto load_w = [&](int cbk) {
 #pragma unroll
         for (int j = 0; j < BIT; ++j) {
             const int i = min((int)threadIdx.x + j * 512, NB4 - 1);
             const int q = i / (SEG / 4), r = i % (SEG / 4);
-            rb[j] = reinterpret_cast<const f32x4*>(p.wpk + ((size_t)q * nblk + cbk) * SEG)[r];
+            rbw[j] = reinterpret_cast<const f32x4*>(p.wpk + ((size_t)(g * NT + q) * nblk + cbk) * SEG)[r];
         }
-#pragma unroll
-        for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sW + cbk * NT * SEG)[min((int)threadIdx.x + j * 512, NB4 - 1)] = rb[j];
         if (SC) {
-            f32x4 rs[SIT];
 #pragma unroll
             for (int j = 0; j < SIT; ++j) {
                 const int i = min((int)threadIdx.x + j * 512, NT * TS / 4 - 1);
                 const int q = i / (TS / 4), r = i % (TS / 4);
-                rs[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)q * nblk + cbk) * TS)[r];
+                rsw[j] = reinterpret_cast<const f32x4*>(p.wsc + ((size_t)(g * NT + q) * nblk + cbk) * TS)[r];
             }
-#pragma unroll
-            for (int j = 0; j < SIT; ++j) reinterpret_cast<f32x4*>(sS + cbk * NT * TS)[min((int)threadIdx.x + j * 512, NT * TS / 4 - 1)] = rs[j];
         }
+    };
+    auto store_w = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sW + slot * NT * SEG)[min((int)threadIdx.x + j * 512, NB4 - 1)] = rbw[j];
+        if (SC) {
+#pragma unroll
+            for (int j = 0; j < SIT; ++j) reinterpret_cast<f32x4*>(sS + slot * NT * TS)[min((int)threadIdx.x + j * 512, NT * TS / 4 - 1)] = rsw[j];
+        }
+    };
+    if (WST) {
+        load_w(0);
+        store_w(0);
+        load_w(1 % nblk);
+    } else {
+        for (int cbk = 0; cbk < nblk; ++cbk) { load_w(cbk); store_w(cbk); }
     }
     // per-channel epilogue constants: one channel group, so they never change
     float e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = nt * 16 + i16;
+        const int co = g * 16 * NT + nt * 16 + i16;
         e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = 0.f;
         if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
         if (SC) scb[nt] = p.sc_bias[co];
@@ -1390,7 +1407,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
             else store_pixel<false, BF, false>(a_img, ra[kb], tab, tp);
         }
     };
-    auto mfma_block = [&](int buf, int kb, int cb) {
+    auto mfma_block = [&](int buf, int kb, int cb) {      // cb: weight slot in LDS
         const float* a_img = sA + buf * AB + kb * (LH * RS);
         const float* b_img = sW + cb * (NT * SEG);
         // valid taps of this parity class, ascending ky then kx:
@@ -1449,9 +1466,9 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
                     accs[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[cg], bs[nt][cg], accs[nt], 0, 0, 0);
         }
     };
-    auto mfma_item = [&](int buf, int ci) {
+    auto mfma_item = [&](int buf, int ci, int it) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) mfma_block(buf, kb, ci * KB + kb);
+        for (int kb = 0; kb < KB; ++kb) mfma_block(buf, kb, WST ? (it & 1) : ci * KB + kb);
     };
     auto epilogue = [&](const Tile& t) {
 #pragma unroll
@@ -1468,12 +1485,12 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
                     }
                 }
                 const f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
-                const size_t ubase = ((size_t)(t.n * p.H + t.y0 + 8 * (mt >> 1) + py) * p.W + t.x0 + 8 * (mt & 1) + px) * p.Cout + nt * 16;
+                const size_t ubase = ((size_t)(t.n * p.H + t.y0 + 8 * (mt >> 1) + py) * p.W + t.x0 + 8 * (mt & 1) + px) * p.Cout + g * 16 * NT + nt * 16;
                 *reinterpret_cast<f32x4*>(p.out + ubase + lane_out) = vt;
                 acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (SC) {
-                const size_t ubase = ((size_t)(t.n * p.Hs + (t.y0 >> 1) + (wave >> 1) * 4) * p.Ws + (t.x0 >> 1) + (wave & 1) * 4) * p.Cout + nt * 16;
+                const size_t ubase = ((size_t)(t.n * p.Hs + (t.y0 >> 1) + (wave >> 1) * 4) * p.Ws + (t.x0 >> 1) + (wave & 1) * 4) * p.Cout + g * 16 * NT + nt * 16;
                 *reinterpret_cast<f32x4*>(p.out_sc + ubase + lane_sc) =
                     quad_transpose(accs[nt][0] + scb[nt], accs[nt][1] + scb[nt], accs[nt][2] + scb[nt], accs[nt][3] + scb[nt], xj);
                 accs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1505,12 +1522,16 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     write_aff_item(1);
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
+        if (WST && it + 1 < iters) {        // every thread of the workgroup: weight block of iteration it+1 -> the other slot,
+            store_w((it + 1) & 1);          // then the block of iteration it+2 -> registers
+            load_w((it + 2) % nblk);
+        }
         if (it < total_items) {
             if (it + 1 < total_items) write_item(cbr, tpr, is_edge(tr), (it + 1) & 1);
             Tile t2 = tr; int cb2 = cbr;
             next_item(it + 1, t2, cb2, tpr);
             load_item(t2, cb2, tpr);
-            mfma_item(it & 1, cb);
+            mfma_item(it & 1, cb, it);
             if (cb == nitem - 1) epilogue(tc);
             write_aff_item(it & 1);
             tc = tr; cb = cbr; tr = t2; cbr = cb2;
@@ -2296,7 +2317,7 @@ static int subpixel_res_kb(const ConvParams& p);
 // persistent form with the LDS-resident weight panel (subpixel_res): one 512-thread workgroup per CU
 template <int NT, int EPI, bool SC, bool BF, int KB>
 static hipError_t launch_subpixel_res_k(const ConvParams& p, int n, size_t lds, hipStream_t s) {
-    auto kern = subpixel_res<NT, EPI, SC, BF, KB>;
+    auto kern = subpixel_res<NT, EPI, SC, BF, KB, false>;
     static bool attr_done = false;
     static int num_cus = 0;
     if (!attr_done) {
@@ -2315,6 +2336,44 @@ static hipError_t launch_subpixel_res_k(const ConvParams& p, int n, size_t lds, 
     const int grid = std::min(num_cus, (q.total_tiles + 1) / 2);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, q);
     return hipGetLastError();
+}
+
+// streamed-weights form: grid (workgroups per channel group, channel groups)
+template <int NT, int EPI, bool SC, bool BF>
+static hipError_t launch_subpixel_wst_t(const ConvParams& p, int n, size_t lds, int wgs_per_g, hipStream_t s) {
+    auto kern = subpixel_res<NT, EPI, SC, BF, 1, true>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    ConvParams q = p;
+    q.tiles_x = p.W / 16;
+    q.tiles_y = p.H / 16;
+    q.groups = p.Cout / (16 * NT);
+    q.total_tiles = q.tiles_x * q.tiles_y * n;       // per channel group
+    hipLaunchKernelGGL(kern, dim3(wgs_per_g, q.groups), dim3(512), lds, s, q);
+    return hipGetLastError();
+}
+
+// Streamed form: LDS bytes and workgroups per channel group, or 0 when it does not pay (fewer than 2 tiles per half)
+static size_t subpixel_wst_lds(const ConvParams& p, int ct, bool sc, int n, int* wgs_per_g) {
+    static const bool enabled = !(getenv("GSA_SUBWST") && atoi(getenv("GSA_SUBWST")) == 0);
+    static int num_cus = 0;
+    if (!num_cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) num_cus = 256;
+    }
+    if (!enabled || p.Cout % ct) return 0;
+    const int ts = p.bf16 ? 128 : 256, px = p.bf16 ? 8 : 16, rs = 10 * px + (p.bf16 ? 4 : 8);
+    const int nt = ct / 16, groups = p.Cout / ct;
+    const size_t lds = sizeof(float) * ((size_t)2 * nt * 16 * ts + (sc ? (size_t)2 * nt * ts : 0) + 4 * 10 * rs) + 64 * sizeof(float4);
+    const long tiles = (long)(p.H / 16) * (p.W / 16) * n;
+    const int wgs = std::max(1, num_cus / groups);
+    if (lds > 160 * 1024 || tiles < 4L * wgs) return 0;
+    *wgs_per_g = wgs;
+    return lds;
 }
 
 template <int NT, int EPI, bool SC, bool BF>
@@ -2362,9 +2421,13 @@ const char* subpixel_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     static thread_local char buf[112];
     const int ct = subpixel_cout_tile(p.H, p.W, p.Cout, n);
     const bool res = subpixel_res_lds(p, ct, sc, n) != 0;
+    int wgs_per_g = 0;
     if (res)
-        snprintf(buf, sizeof buf, "void gsa::subpixel_res<%d, %d, %s, %s, %d>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
+        snprintf(buf, sizeof buf, "void gsa::subpixel_res<%d, %d, %s, %s, %d, false>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
                  p.bf16 ? "true" : "false", subpixel_res_kb(p));
+    else if (subpixel_wst_lds(p, ct, sc, n, &wgs_per_g))
+        snprintf(buf, sizeof buf, "void gsa::subpixel_res<%d, %d, %s, %s, 1, true>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
+                 p.bf16 ? "true" : "false");
     else
         snprintf(buf, sizeof buf, "void gsa::subpixel_mfma<%d, %d, %s, %s>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
                  p.bf16 ? "true" : "false");
@@ -2392,6 +2455,18 @@ hipError_t launch_subpixel(const ConvParams& p, int epi, bool sc, int n, hipStre
         }
         GSA_SUBR(1, false) GSA_SUBR(2, false) GSA_SUBR(1, true) GSA_SUBR(2, true)
 #undef GSA_SUBR
+    }
+    int wgs_per_g = 0;
+    if (const size_t wlds = subpixel_wst_lds(p, ct, sc, n, &wgs_per_g)) {
+#define GSA_SUBW(NT, BF) \
+        if (ct == 16 * NT && (p.bf16 != 0) == BF) { \
+            if (sc) return launch_subpixel_wst_t<NT, EPI_DEC, true, BF>(p, n, wlds, wgs_per_g, s); \
+            if (epi == EPI_DEC) return launch_subpixel_wst_t<NT, EPI_DEC, false, BF>(p, n, wlds, wgs_per_g, s); \
+            if (epi == EPI_RAW) return launch_subpixel_wst_t<NT, EPI_RAW, false, BF>(p, n, wlds, wgs_per_g, s); \
+            return hipErrorInvalidValue; \
+        }
+        GSA_SUBW(1, false) GSA_SUBW(2, false) GSA_SUBW(4, false) GSA_SUBW(1, true) GSA_SUBW(2, true) GSA_SUBW(4, true)
+#undef GSA_SUBW
     }
 #define GSA_SUB(NT) \
     if (ct == 16 * NT && !p.bf16) { \
