@@ -11,7 +11,8 @@
  * is a hipStream_t as void*; calls are stream-ordered and never synchronise; 0 on success, a negative
  * gsa_status otherwise.  Unlike the inference path these kernels are not order-canonical: sums use float
  * atomics, so results are reproducible to fp32 rounding, not bit for bit; parity is a stated tolerance against
- * a torch-autograd restatement (oracle/ref_train.py).
+ * a torch-autograd restatement (oracle/ref_train.py).  The two BatchNorm operators reduce through one per-device
+ * scratch buffer: issue them from one stream at a time (the trainer uses a single stream).
  */
 #ifndef GSA_TRAIN_H
 #define GSA_TRAIN_H
