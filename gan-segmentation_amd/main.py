@@ -1,5 +1,7 @@
-"""``python -m gan_segmentation_amd.main generate`` -- the `generate` action of reference
-main.py:75-104 with the same ``config.yml`` keys (reference config.yml.example:1-8).
+"""``python -m gan_segmentation_amd.main [generate|train|evaluate]`` -- the actions of reference main.py:44-104
+with the same ``config.yml`` keys (reference config.yml.example:1-8); `generate` is the hot path, `train` and
+`evaluate` drive ``SegSolver.fit`` / ``SegSolver.evaluate``.  The Tk `annotation` GUI
+is out of scope.
 
 Writes ``img_%06d.jpg`` (RGB image; the reference flips to BGR only because cv2 expects it)
 and ``mask_%06d.png`` (single channel, class index) into BASE_DIR/dataset/train_generated.
@@ -61,18 +63,53 @@ def generate(cfg, limit=None, workers=None):
     return 0
 
 
+def _solver(cfg, keep_weights=False):
+    from .seg_solver import SegSolver
+    from .weights import GAN_MAX_RES_LOG2
+    root_dir, gan = cfg["BASE_DIR"], cfg["GAN"]
+    gpu_ids = list(cfg.get("SOLVER_GPU_IDS", cfg.get("GAN_GPU_IDS", [0])))[:1]
+    return SegSolver(GAN_MAX_RES_LOG2[gan], os.path.join(root_dir, "data"), os.path.join(root_dir, "checkpoints"),
+                     gpu_ids=gpu_ids, keep_weights=keep_weights, precision=cfg.get("PRECISION", "fp32"))
+
+
+def train(cfg, epochs=None):
+    """The `train` action (reference main.py:54-60): fit the decoder on BASE_DIR/data, save the checkpoint."""
+    solver = _solver(cfg, keep_weights=False)
+    history = solver.fit(epochs=epochs, log=print)
+    print("final loss: %.6f" % history[-1])
+    return 0
+
+
+def evaluate(cfg):
+    """The `evaluate` action (reference main.py:61-73) over BASE_DIR/eval."""
+    solver = _solver(cfg)
+    if not solver.is_trained:
+        print("train Decoder first!")
+        return -1
+    result = solver.evaluate(os.path.join(cfg["BASE_DIR"], "eval"))
+    print(", ".join("%s: %.4f" % (name, value) for name, value in result))
+    return 0
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("action", nargs="?", choices=("annotation", "train", "evaluate", "generate"), default="generate")
     ap.add_argument("--config", default="config.yml")
     ap.add_argument("--limit", type=int, default=None, help="override GENERATE_NUM")
     ap.add_argument("--workers", type=int, default=None, help="encoder threads (default: the CPU share of the process)")
+    ap.add_argument("--epochs", type=int, default=None, help="train: override the reference's 24 epochs")
     args = ap.parse_args(argv)
-    if args.action != "generate":
-        print("only the `generate` action is implemented by the MI355X path (SURVEY.md section 8)")
+    if args.action == "annotation":
+        print("the Tk annotation GUI is out of scope (SURVEY.md section 8); annotation_io.export_sample writes the "
+              "img/feat files it saves, for masks drawn elsewhere")
         return 2
     np.random.seed(0)
-    return generate(load_config_file(args.config), args.limit, args.workers)
+    cfg = load_config_file(args.config)
+    if args.action == "train":
+        return train(cfg, args.epochs)
+    if args.action == "evaluate":
+        return evaluate(cfg)
+    return generate(cfg, args.limit, args.workers)
 
 
 if __name__ == "__main__":

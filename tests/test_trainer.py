@@ -111,3 +111,36 @@ def test_solver_fit_learns_and_saves(tmp_path):
     assert result["accuracy"] > 0.9 and result["mean-iou"] > 0.75, result
     again = SegSolver(mr, str(data), str(ckpt), gpu_ids=[0], in_channels=chans)                 # the saved checkpoint loads
     assert again.is_trained and dict(again.evaluate(str(data)))["accuracy"] == result["accuracy"]
+
+
+def test_cli_train_and_evaluate_at_bedrooms_size(tmp_path, capsys):
+    """`main.py train` / `main.py evaluate` (reference main.py:54-73) on a BASELINE-size decoder (bedrooms, 256^2)."""
+    import yaml
+    from PIL import Image
+    from gan_segmentation_amd import annotation_io, main as cli, weights as W
+    dcfg = W.decoder_config(W.GAN_MAX_RES_LOG2["bedrooms"])
+    chans = dcfg["in_channels"]
+    R = 4 << (len(chans) - 1)
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:R, 0:R]
+    for sub in ("data", "eval"):
+        for i in range(2):
+            feats = [rng.standard_normal((c, 4 << l, 4 << l)).astype(np.float32) for l, c in enumerate(chans)]
+            inside = (yy - R / 2) ** 2 + (xx - R / 2 - 10 * i) ** 2 < (R / 3) ** 2
+            feats[-1][:4] += np.where(inside, 2.0, -2.0)[None]
+            annotation_io.export_sample(str(tmp_path / sub), i, np.zeros((R, R, 3), np.uint8), feats)
+            Image.fromarray(np.where(inside, 230, 128).astype(np.uint8), "L").save(str(tmp_path / sub / ("mask_%06d.png" % i)))
+    cfg = {"BASE_DIR": str(tmp_path), "GAN": "bedrooms", "GAN_DIR": str(tmp_path), "GAN_GPU_IDS": [0], "SOLVER_GPU_IDS": [0],
+           "GAN_BATCH_SIZE_PER_GPU": 2, "ANNOTATION": "segmentation"}
+    (tmp_path / "config.yml").write_text(yaml.safe_dump(cfg))
+    assert cli.main(["evaluate", "--config", str(tmp_path / "config.yml")]) == -1          # no checkpoint yet
+    assert cli.main(["train", "--config", str(tmp_path / "config.yml"), "--epochs", "6"]) == 0
+    assert (tmp_path / "checkpoints" / "checkpoint_last.params").exists()
+    assert cli.main(["evaluate", "--config", str(tmp_path / "config.yml")]) == 0
+    out = capsys.readouterr().out
+    assert "train Decoder first!" in out and "Epoch[6] Train-total-loss=" in out
+    line = [l for l in out.splitlines() if l.startswith("accuracy:")][-1]
+    acc = float(line.split(",")[0].split(":")[1])
+    losses = [float(l.split("=")[1]) for l in out.splitlines() if "Train-total-loss=" in l]
+    assert len(losses) == 6 and losses[-1] < 0.9 * losses[0], losses          # 12 Adam steps at lr 1e-4: falling, not converged
+    assert acc > 0.6, line
