@@ -1728,41 +1728,47 @@ __global__ void pixelnorm_kernel(const float* z, float* out, int n, int L) {
 // truncated latent x_k = latent_avg[k]*(1-psi_l) + w[k]*psi_l (reference :158-163), formed on
 // the fly.  Every output is one k-ordered fmaf chain (canonical order); the K loop only walks
 // LDS, so the 512-step chain costs ~2 us instead of 512 dependent global-load round trips.
-template <bool STYLE>
+// JB = output columns per workgroup: 64 for the wide style affines, 16 for the 512-wide mapping layers (32 workgroups
+// instead of 8: the eight layers are a serial latency chain at the head of every step)
+template <bool STYLE, int JB>
 __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const float* WT, const float* b, float* y,
                                                         int n, int K, int J, int act, const float* avg,
                                                         const float* psi, const int* col_layer) {
     constexpr int KC = 128;                         // K rows per LDS pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sW = smem;                               // [KC][64]
-    float* sX = sW + KC * 64;                       // [16][KC]
+    constexpr int G = 256 / JB, SPT = 16 / G;       // sample groups, samples per thread (16 samples per pass)
+    float* sW = smem;                               // [KC][JB]
+    float* sX = sW + KC * JB;                       // [16][KC]
     float* sAvg = sX + 16 * KC;                     // [KC] (STYLE)
-    const int tid = threadIdx.x, jl = tid & 63, ng = tid >> 6;
-    const int j0 = blockIdx.x * 64, j = j0 + jl;
+    const int tid = threadIdx.x, jl = tid % JB, ng = tid / JB;
+    const int j0 = blockIdx.x * JB, j = j0 + jl;
     const int jc = j < J ? j : J - 1;
     float ps = 1.0f, om = 0.0f;
     if (STYLE) { ps = psi[col_layer[jc]]; om = 1.0f - ps; }
     for (int n0 = 0; n0 < n; n0 += 16) {
         const int nn = min(16, n - n0);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};        // samples n0 + ng + 4*i
+        float acc[SPT];                             // samples n0 + ng + G*i
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) acc[i] = 0.f;
         for (int k0 = 0; k0 < K; k0 += KC) {
             __syncthreads();
-            // weight panel: KC x 64 floats = KC*16 float4, coalesced rows of 256 B
-            f32x4 rw[KC * 16 / 256];
+            // weight panel: KC x JB floats, coalesced rows of 4*JB bytes
+            constexpr int Q4 = JB / 4, NW4 = KC * Q4 / 256;
+            f32x4 rw[NW4];
 #pragma unroll
-            for (int i = 0; i < KC * 16 / 256; ++i) {
-                const int idx = tid + i * 256, kr = idx >> 4, c4 = (idx & 15) * 4;
+            for (int i = 0; i < NW4; ++i) {
+                const int idx = tid + i * 256, kr = idx / Q4, c4 = (idx % Q4) * 4;
                 const int col = min(j0 + c4, J - 4);
                 rw[i] = *reinterpret_cast<const f32x4*>(WT + (size_t)(k0 + kr) * J + col);
             }
             for (int idx = tid; idx < nn * KC; idx += 256) sX[idx] = x[(size_t)(n0 + idx / KC) * K + k0 + idx % KC];
             if (STYLE) for (int idx = tid; idx < KC; idx += 256) sAvg[idx] = avg[k0 + idx];
 #pragma unroll
-            for (int i = 0; i < KC * 16 / 256; ++i) reinterpret_cast<f32x4*>(sW)[tid + i * 256] = rw[i];
+            for (int i = 0; i < NW4; ++i) reinterpret_cast<f32x4*>(sW)[tid + i * 256] = rw[i];
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int s = ng + 4 * i;
+            for (int i = 0; i < SPT; ++i) {
+                const int s = ng + G * i;
                 if (s < nn) {
                     float a = acc[i];
                     const float* xs = sX + s * KC;
@@ -1770,7 +1776,7 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const fl
                     for (int k = 0; k < KC; ++k) {
                         float xv = xs[k];
                         if (STYLE) { const float t0 = sAvg[k] * om; const float t1 = xv * ps; xv = t0 + t1; }
-                        a = fmaf(xv, sW[k * 64 + jl], a);
+                        a = fmaf(xv, sW[k * JB + jl], a);
                     }
                     acc[i] = a;
                 }
@@ -1779,8 +1785,8 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const fl
         if (j < J) {
             const float bj = b[j];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int s = ng + 4 * i;
+            for (int i = 0; i < SPT; ++i) {
+                const int s = ng + G * i;
                 if (s < nn) {
                     const float v = acc[i] + bj;
                     y[(size_t)(n0 + s) * J + j] = act ? lrelu(v) : v;
@@ -2512,8 +2518,8 @@ hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_
 
 hipError_t launch_dense(const float* x, const float* WT, const float* b, float* y, int n, int K, int J, int act, hipStream_t s) {
     if (K % 128 || J % 4) return hipErrorInvalidValue;
-    const size_t lds = sizeof(float) * (128 * 64 + 16 * 128 + 128);
-    hipLaunchKernelGGL(dense_lds_kernel<false>, dim3((J + 63) / 64), dim3(256), lds, s, x, WT, b, y, n, K, J, act,
+    const size_t lds = sizeof(float) * (128 * 16 + 16 * 128 + 128);
+    hipLaunchKernelGGL((dense_lds_kernel<false, 16>), dim3((J + 15) / 16), dim3(256), lds, s, x, WT, b, y, n, K, J, act,
                        (const float*)nullptr, (const float*)nullptr, (const int*)nullptr);
     return hipGetLastError();
 }
@@ -2522,7 +2528,7 @@ hipError_t launch_styles(const float* w, const float* avg, const float* psi, con
                          const int* col_layer, float* styles, int n, int K, int J, hipStream_t s) {
     if (K % 128 || J % 4) return hipErrorInvalidValue;
     const size_t lds = sizeof(float) * (128 * 64 + 16 * 128 + 128);
-    hipLaunchKernelGGL(dense_lds_kernel<true>, dim3((J + 63) / 64), dim3(256), lds, s, w, WT, b, styles, n, K, J, 0, avg, psi, col_layer);
+    hipLaunchKernelGGL((dense_lds_kernel<true, 64>), dim3((J + 63) / 64), dim3(256), lds, s, w, WT, b, styles, n, K, J, 0, avg, psi, col_layer);
     return hipGetLastError();
 }
 
