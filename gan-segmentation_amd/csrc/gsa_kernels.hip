@@ -2158,8 +2158,8 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int NBUF = (Q <= 2 && !SC && TH == 16) ? 2 : 1;   // must match the kernel's DB
     // resident weights: one channel group and a whole panel of at most 40 KB (see the kernel)
     const int nblk_all = (p.C0 + p.C1) / 16;
-    const bool wres = NBUF == 2 && p.Cout == COUT_T && (size_t)nblk_all * Q * 9 * TS * sizeof(float) <= 40 * 1024 &&
-                      !(getenv("GSA_WRES") && atoi(getenv("GSA_WRES")) == 0);
+    static const bool wres_enabled = !(getenv("GSA_WRES") && atoi(getenv("GSA_WRES")) == 0);
+    const bool wres = wres_enabled && NBUF == 2 && p.Cout == COUT_T && (size_t)nblk_all * Q * 9 * TS * sizeof(float) <= 40 * 1024;
     if (NBUF == 1 && p.C0 > 512 && p.aff0) return hipErrorInvalidValue;   // AdaIN table registers sized for <= 512 channels
     const int wslots = wres ? nblk_all * Q * 9 * TS : NBUF * Q * 9 * TS;
     const size_t lds = sizeof(float) * (NBUF * (TH + 2) * RS + wslots + (SC ? Q * TS : 0)) +
