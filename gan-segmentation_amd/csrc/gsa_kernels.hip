@@ -25,6 +25,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef GSA_NO_XCD_REMAP
+#define GSA_NO_XCD_REMAP 0
+#endif
+
 namespace gsa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -175,6 +179,14 @@ __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const floa
 // layers.)
 struct WorkTile { int n, g, y0, x0, row; };   // row = tile index inside the image
 
+// Workgroups are dispatched round-robin over the 8 XCDs (workgroup i -> XCD i % 8) and each XCD has its own L2.
+// Persistent kernels therefore hand XCD x the x-th contiguous eighth of the work: the vertical neighbours of a
+// tile (one image row of tiles further on) are then processed on the same XCD at about the same time, and the
+// halo rows they share are served by that L2 instead of being fetched from HBM once per XCD.
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    return (nb & 7) == 0 && !GSA_NO_XCD_REMAP ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+}
+
 //
 // BF = bf16 MFMA mode (BASELINE config 5): operands are rounded to bf16 when they are staged (inputs after
 // the fp32 AdaIN, weights on the host), one v_mfma_f32_16x16x16_bf16 per (tap, 16-channel block) replaces four
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 
     // contiguous range of work tiles of this workgroup; order (n, g, ty, tx), tx fastest
     const int chunk = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int w_begin = blockIdx.x * chunk;
+    const int w_begin = xcd_block(blockIdx.x, gridDim.x) * chunk;
     const int w_end = min(p.total_tiles, w_begin + chunk);
     if (w_begin >= w_end) return;
     // Index arithmetic is kept off the vector ALU: f32 MFMAs and VALU instructions do not co-execute on a SIMD
@@ -1289,7 +1301,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
 
     // contiguous range of tiles, order (n, ty, tx)
     const int chunk = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    int w_begin = blockIdx.x * chunk;
+    int w_begin = xcd_block(blockIdx.x, gridDim.x) * chunk;
     int w_end = min(p.total_tiles, w_begin + chunk);
     if (w_begin >= w_end) return;                  // whole workgroup
     const int first_half = (w_end - w_begin + 1) >> 1;
