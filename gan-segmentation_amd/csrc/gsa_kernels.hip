@@ -178,6 +178,7 @@ __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const floa
 // in-kernel stamps showed 57k-cycle load phases and 7x-stretched MFMA phases on the 16-channel
 // layers.)
 struct WorkTile { int n, g, y0, x0, row; };   // row = tile index inside the image
+constexpr int kDirectRows = 64;               // accumulator rows per sample of the "direct statistics" form (power of two)
 
 // Workgroups are dispatched round-robin over the 8 XCDs (workgroup i -> XCD i % 8) and each XCD has its own L2.
 // Persistent kernels therefore hand XCD x the x-th contiguous eighth of the work: the vertical neighbours of a
@@ -424,7 +425,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
     // Direct statistics (launcher: persistent double-buffered EPI_SYNTH launches): a wave keeps its fixed-point
     // sums in registers across the tiles of one (sample, channel group) and adds them to acc[n][c] with one
     // 64-bit atomic per channel when the group changes -- instead of a 16-byte partial row per tile and wave
-    // (16384 rows per sample at 1024^2, which finalize_kernel then needed 53 us to re-read).
+    // (16384 rows per sample at 1024^2, which finalize_kernel then needed 53 us to re-read).  The atomics go to
+    // kDirectRows zero-initialised rows per sample (row = workgroup & 63): all 3072 waves adding to ONE row made
+    // the 1024^2 layer 2.4x slower at batch 1 (same-address atomics serialise).
     const bool stats_direct = EPI == EPI_SYNTH && p.stats_direct;
     unsigned long long dI1[NT], dI2[NT];
 #pragma unroll
@@ -435,8 +438,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
             unsigned long long I1 = dI1[nt], I2 = dI2[nt];
             I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
             I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
-            if (lane < 16) {
-                StatPart* a = p.acc + (size_t)t.n * p.Cout + t.g * COUT_T + (wn * NT + nt) * 16 + i16;
+            if (lane < 16) {      // kDirectRows zeroed rows per sample: workgroups spread over them, finalize_kernel sums them
+                StatPart* a = p.partials + ((size_t)t.n * p.prow + (blockIdx.x & (kDirectRows - 1))) * p.Cout + t.g * COUT_T + (wn * NT + nt) * 16 + i16;
                 atomicAdd(&a->s1, I1);
                 atomicAdd(&a->s2, I2);
             }
@@ -2213,8 +2216,14 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     // prologue); long tiles pipeline inside the tile already and run ~8 % faster one tile per workgroup
     const bool persistent = (p.C0 + p.C1) <= 32 && q.total_tiles > num_cus * wgs_per_cu;
     const int grid = persistent ? num_cus * wgs_per_cu : q.total_tiles;
-    q.stats_direct = (EPI == EPI_SYNTH && NBUF == 2 && persistent && p.acc != nullptr) ? 1 : 0;
-    if (p.stat_rows_host) *p.stat_rows_host = q.stats_direct ? 0 : q.prow;
+    static const bool direct_enabled = !(getenv("GSA_STATS_DIRECT") && atoi(getenv("GSA_STATS_DIRECT")) == 0);
+    q.stats_direct = (direct_enabled && EPI == EPI_SYNTH && NBUF == 2 && persistent && p.partials != nullptr) ? 1 : 0;
+    if (q.stats_direct) {
+        q.prow = kDirectRows;
+        hipError_t e = hipMemsetAsync(p.partials, 0, sizeof(StatPart) * (size_t)n * kDirectRows * p.Cout, s);
+        if (e != hipSuccess) return e;
+    }
+    if (p.stat_rows_host) *p.stat_rows_host = q.prow;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, s, q);
     return hipGetLastError();
 }
