@@ -53,6 +53,10 @@ class Api:
                            "g.build()'` (there is no CPU fallback)" % path)
         self.path = path
         self.prefix = prefix
+        if prefix == "gsa_":
+            # The process must end up with ONE HIP runtime: torch brings its own libamdhip64, and a library that pulled
+            # in another copy first leaves the GPU invisible to one of the two -- so torch is imported before the dlopen.
+            import torch  # noqa: F401
         self.lib = ctypes.CDLL(path)
         c = ctypes
         vp, i32 = c.c_void_p, c.c_int32
