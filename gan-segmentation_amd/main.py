@@ -63,6 +63,21 @@ def generate(cfg, limit=None, workers=None):
     return 0
 
 
+def export_for_annotation(cfg, count):
+    """Headless stand-in for the sampling half of the annotator (reference seg_annotator.py:286-337): generate `count`
+    samples and save what the GUI saves next to a drawn mask -- BASE_DIR/data/img_%06d.jpg and feat_%06d.pickle."""
+    from . import annotation_io
+    from .image_generator import ImageGenerator
+    gpu = list(cfg["GAN_GPU_IDS"])[0]
+    netG = ImageGenerator(gpu_ids=[gpu], gan_dir=cfg["GAN_DIR"], gan=cfg["GAN"], batch_size=cfg["GAN_BATCH_SIZE_PER_GPU"],
+                          precision=cfg.get("PRECISION", "fp32"), seed=int(cfg.get("SEED", 0)))
+    dst = os.path.join(cfg["BASE_DIR"], "data")
+    for i, (img, feats) in enumerate(netG.get_images(count)):
+        annotation_io.export_sample(dst, i, img, feats)
+    print("wrote %d samples (img + feat) to %s" % (count, dst))
+    return 0
+
+
 def _solver(cfg, keep_weights=False):
     from .seg_solver import SegSolver
     from .weights import GAN_MAX_RES_LOG2
@@ -98,13 +113,16 @@ def main(argv=None):
     ap.add_argument("--limit", type=int, default=None, help="override GENERATE_NUM")
     ap.add_argument("--workers", type=int, default=None, help="encoder threads (default: the CPU share of the process)")
     ap.add_argument("--epochs", type=int, default=None, help="train: override the reference's 24 epochs")
+    ap.add_argument("--count", type=int, default=None, help="annotation: number of samples to generate and export")
     args = ap.parse_args(argv)
-    if args.action == "annotation":
-        print("the Tk annotation GUI is out of scope (SURVEY.md section 8); annotation_io.export_sample writes the "
-              "img/feat files it saves, for masks drawn elsewhere")
-        return 2
     np.random.seed(0)
     cfg = load_config_file(args.config)
+    if args.action == "annotation":
+        if args.count is None:
+            print("the Tk annotation GUI is out of scope (SURVEY.md section 8); `annotation --count N` writes the img/feat "
+                  "files the GUI saves for N generated samples (masks are then drawn with any image editor)")
+            return 2
+        return export_for_annotation(cfg, args.count)
     if args.action == "train":
         return train(cfg, args.epochs)
     if args.action == "evaluate":

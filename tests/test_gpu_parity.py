@@ -217,6 +217,12 @@ def test_cli_generate_writes_dataset(torch_cuda, tmp_path):
     mask = np.asarray(Image.open(out / "mask_000001.png"))
     assert img.size == (256, 256) and img.mode == "RGB"
     assert mask.shape == (256, 256) and mask.dtype == np.uint8 and set(np.unique(mask)) <= {0, 1}
+    # `annotation --count N`: the img/feat files the annotator GUI saves, loadable by the few-shot reader
+    assert cli.main(["annotation", "--config", str(tmp_path / "config.yml")]) == 2            # no GUI here
+    assert cli.main(["annotation", "--config", str(tmp_path / "config.yml"), "--count", "3"]) == 0
+    from gan_segmentation_amd import annotation_io
+    m_, img_a, feats = annotation_io.load_sample(str(base / "data"), 2)
+    assert m_ is None and img_a.shape == (256, 256, 3) and len(feats) == 7 and feats[-1].shape == (64, 256, 256)
     # without a decoder checkpoint the reference prints "train Decoder first!" and exits -1
     (base / "checkpoints" / "checkpoint_last.params").unlink()
     assert cli.main(["generate", "--config", str(tmp_path / "config.yml")]) == -1
