@@ -85,9 +85,10 @@ class PairGatherer:
     transfer over xGMI hides behind the next batch's kernels.  ``result(slot)`` on ``dst`` = per-rank views
     ``[(img (n,R,R,ch), mask (n,R,R))]`` in rank order (global sample order), no copy."""
 
-    def __init__(self, n, R, channels=3, device="cpu", dst=0, depth=2, group=None):
+    def __init__(self, n, R, channels=3, device="cpu", dst=0, depth=2, group=None, force_collective=False):
         self.n, self.R, self.ch, self.dst, self.depth, self.group = n, R, channels, dst, depth, group
-        self.active = dist.is_initialized() and dist.get_world_size(group) > 1
+        # force_collective: issue the gather even in a one-rank group (exercises the RCCL call path on a single GPU)
+        self.active = dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
         self.world = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
         self.img_bytes = n * R * R * channels

@@ -2,6 +2,8 @@
 
 The bar is BIT-EXACT equality for every output (fp32 rgb, features, logits, u8 image, u8 mask):
 the kernels implement the oracle's canonical fp32 evaluation order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -243,3 +245,45 @@ def test_config4_bedrooms_batch64_and_workspace_growth(torch_cuda):
     assert_same(i64[63:].cpu().numpy(), i1.cpu().numpy(), "last sample image")
     assert_same(m64[63:].cpu().numpy(), m1.cpu().numpy(), "last sample mask")
     assert 0.001 < m64.float().mean().item() < 0.999
+
+
+_RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29733")
+import numpy as np, torch, torch.distributed as dist
+from gan_segmentation_amd import dist as gdist
+from tests.common import reduced_setup
+from gan_segmentation_amd.image_generator import ImageGenerator
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)           # RCCL, one rank: the collective call path of bench.py --gpus N
+gcfg, gp, dcfg, dp, z, noise = reduced_setup(7, batch=3)
+gen = ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[0], batch_size=3)
+ref_img, ref_mask = gen.generate_batch(z, noise)
+gat = gdist.PairGatherer(3, 128, 3, device=torch.device("cuda", 0), depth=2, force_collective=True)
+for k in range(4):                                             # overlapped: wait only when a slot comes round again
+    slot = k & 1
+    gat.wait(slot)
+    gen.generate_batch(z, noise, out=gat.buffers(slot))
+    gat.submit(slot)
+gat.wait_all()
+torch.cuda.synchronize()
+for slot in (0, 1):
+    (img, mask), = gat.result(slot)
+    assert torch.equal(img, ref_img) and torch.equal(mask, ref_mask)
+gi, gm = gdist.gather_pairs(ref_img, ref_mask)                 # the blocking form degenerates to identity at one rank
+assert gi is ref_img
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_GATHER_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pair_gatherer_over_rccl_single_rank(torch_cuda, tmp_path):
+    """The asynchronous gather of bench.py (dist.PairGatherer) through RCCL itself -- a one-rank group on this GPU:
+    async gather into views of one preallocated tensor, stream-ordered wait, results identical to the direct call."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL_GATHER_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
