@@ -25,6 +25,11 @@
 #include <cstdio>
 #include <cstdlib>
 
+// wave priority during the MFMA phase of conv3x3_mfma (the wave multiplying wins the SIMD's issue slot over the wave
+// staging): +0.5-1 % on the step in A/B runs; the same in the stride-2 kernels measured -0.5 % and is not used
+#ifndef GSA_MFMA_PRIO
+#define GSA_MFMA_PRIO 2
+#endif
 #ifndef GSA_NO_XCD_REMAP
 #define GSA_NO_XCD_REMAP 0
 #endif
@@ -512,6 +517,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #ifdef GSA_DBG_HOOKS
         if (p.dbg & 16) return;      // timing-only: no MFMA phase
 #endif
+        __builtin_amdgcn_s_setprio(GSA_MFMA_PRIO);      // the wave in its MFMA phase wins the SIMD's issue slot
         const float* a_img = sA + buf * (LH * RS);
         const float* b_img = sB + (wres ? cb_res : buf) * (Q * SEG);
         if constexpr (BF) {
@@ -570,6 +576,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
                             accs[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], bs[nt][cg], accs[mt][nt], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     };
 
     if constexpr (DB) {
