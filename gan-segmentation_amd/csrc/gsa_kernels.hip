@@ -30,6 +30,9 @@
 #ifndef GSA_MFMA_PRIO
 #define GSA_MFMA_PRIO 2
 #endif
+#ifndef GSA_OPERAND_PIPELINE
+#define GSA_OPERAND_PIPELINE 1
+#endif
 #ifndef GSA_NO_XCD_REMAP
 #define GSA_NO_XCD_REMAP 0
 #endif
@@ -548,6 +551,33 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
             return;
         }
         // ---- MFMA: K order (tap, cg, ci) inside the block
+        if constexpr (!SC && NT <= 2 && GSA_OPERAND_PIPELINE) {
+            // operands of tap t+1 are read from LDS before the MFMAs of tap t are issued (explicit double buffer)
+            f32x4 a2[2][MT], b2[2][NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a2[0][mt] = *reinterpret_cast<const f32x4*>(a_img + abase[mt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b2[0][nt] = *reinterpret_cast<const f32x4*>(b_img + bbase + nt * SEG);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) {
+                    const int toff = ((tap + 1) / 3) * RS + ((tap + 1) % 3) * 16;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a2[(tap + 1) & 1][mt] = *reinterpret_cast<const f32x4*>(a_img + abase[mt] + toff);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b2[(tap + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(b_img + bbase + nt * SEG + (tap + 1) * 256);
+                }
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tap & 1][mt][cg], b2[tap & 1][nt][cg], acc[mt][nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            return;
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = (tap / 3) * RS + (tap % 3) * 16;
