@@ -739,8 +739,6 @@ int gsa_decoder_commit(gsa_ctx* c) {
                 if (int rc = upload_mfma(c, h, &d.sc_w, T)) return rc;
                 h.assign(b, b + d.cs);
                 if (int rc = upload(c, h, &d.sc_b, T)) return rc;
-            } else if (i > 0) {
-                return fail(c, GSA_ERR_INVALID, "decoder level %d: identity shortcut over a concatenated input is not supported", i);
             }
         } else {
             const std::string pf = "main_block_" + std::to_string(i) + ".0";
@@ -967,7 +965,8 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 cp.wpk = d.b_w; cp.Cout = d.cs; cp.out = c->prev[i];
                 cp.bias = d.b_b; cp.bn_s = d.b_s; cp.bn_rm = d.b_rm; cp.bn_beta = d.b_beta;
                 if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = R2 >= 16 ? 1 : 0; }   // sub-pixel conv a stores the shortcut at input resolution
-                else { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
+                else if (i == 0) { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
+                else { cp.resid = c->prev[i - 1]; cp.resid1 = c->cvt[i]; cp.res_c0 = d.F; cp.resid_up = 1; }   // ... over concat(prev, cvt)
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
                 Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));

@@ -35,6 +35,7 @@ struct ConvParams {
     // EPI_DEC: conv bias -> BatchNorm(inference) -> LeakyReLU [-> + resid]
     const float* bias; const float* bn_s; const float* bn_rm; const float* bn_beta;
     const float* resid; int resid_up;   // resid_up: residual lives at half resolution (identity shortcut)
+    const float* resid1; int res_c0;    // residual = concat(resid [res_c0 channels], resid1 [Cout - res_c0]); resid1 null: one tensor
     // fused 1x1 shortcut of DecoderResBlock (second output)
     const float* wsc; const float* sc_bias; float* out_sc;
     int tiles_x, tiles_y, groups, total_tiles;   // filled by the launcher

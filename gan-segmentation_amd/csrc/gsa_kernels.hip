@@ -400,7 +400,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
     // addresses = wave-uniform base of the patch (scalar ALU) + a per-lane 32-bit offset that never changes
     const int ru = p.resid_up;      // 1: the residual lives at half resolution
     const unsigned lane_out = (unsigned)((prow_in_patch * p.W + xj) * p.Cout + cq4);
-    const unsigned lane_res = (unsigned)(((prow_in_patch >> ru) * (p.W >> ru) + (xj >> ru)) * p.Cout + cq4);
+    const int res_cs0 = p.resid1 ? p.res_c0 : p.Cout, res_cs1 = p.Cout - p.res_c0;   // channel strides of the residual source(s)
+    const unsigned lane_rpix = (unsigned)((prow_in_patch >> ru) * (p.W >> ru) + (xj >> ru));
+    const unsigned lane_res0 = lane_rpix * res_cs0 + cq4, lane_res1 = lane_rpix * res_cs1 + cq4;
     const unsigned lane_nz = (unsigned)(prow_in_patch * p.W);
     auto epilogue_loads = [&](const WorkTile& tc) {
 #pragma unroll
@@ -421,11 +423,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int pidx = wm * MT + mt, pr = pidx / PW, pc = pidx % PW;
-                const float* rbase = p.resid + ((size_t)(tc.n * (p.H >> ru) + ((tc.y0 + pr * 4) >> ru)) * (p.W >> ru) + ((tc.x0 + pc * 4) >> ru)) * p.Cout
-                                     + tc.g * COUT_T + wn * NT * 16;
+                const size_t rpix = (size_t)(tc.n * (p.H >> ru) + ((tc.y0 + pr * 4) >> ru)) * (p.W >> ru) + ((tc.x0 + pc * 4) >> ru);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    rr[mt][nt] = *reinterpret_cast<const f32x4*>(rbase + nt * 16 + lane_res);
+                for (int nt = 0; nt < NT; ++nt) {
+                    // the residual may be the channel concatenation of two tensors (identity shortcut over concat(prev, cvt)):
+                    // channels [0, res_c0) live in resid, the rest in resid1; a 16-channel group never straddles the split
+                    const int cch = tc.g * COUT_T + (wn * NT + nt) * 16;
+                    const bool second = p.resid1 != nullptr && cch >= p.res_c0;
+                    const float* rsrc = (second ? p.resid1 : p.resid) + rpix * (second ? res_cs1 : res_cs0) + (second ? cch - p.res_c0 : cch);
+                    rr[mt][nt] = *reinterpret_cast<const f32x4*>(rsrc + (second ? lane_res1 : lane_res0));
+                }
             }
         }
     };

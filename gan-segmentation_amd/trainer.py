@@ -35,6 +35,7 @@ class DecoderTrainer:
         self.seed = seed
         self.keep = dropout_keep if cfg.get("use_dropout", True) else 1.0
         self.t = 0
+        self._eyes = {}
         shapes = _weights.decoder_param_shapes(cfg)
         self.p, self.g, self.m, self.v = {}, {}, {}, {}
         for name, shape in shapes.items():
@@ -101,10 +102,8 @@ class DecoderTrainer:
                 if sc_name + ".weight" in p:
                     sc, _ = ops.conv(src0, src1, p[sc_name + ".weight"], p[sc_name + ".bias"], up=1)
                     prev = ops.add(sc, y)
-                else:   # identity shortcut on the upsampled input (in_c == conv_size, only without concat)
-                    if src1 is not None:
-                        raise NotImplementedError("identity shortcut with a concatenated input")
-                    prev = self._identity_up_add(src0, y)
+                else:   # identity shortcut on the upsampled (possibly concatenated) input: in_c == conv_size
+                    prev = self._identity_up_add(src0, src1, y)
                 rec.update(a_raw=a_raw, a=a, a_stats=a_stats, b_raw=b_raw, b_stats=b_stats)
             else:
                 fn = "main_block_%d.0" % i
@@ -136,8 +135,8 @@ class DecoderTrainer:
                 if sc_name + ".weight" in p:
                     ops.conv_wgrad(src0, src1, dy, 1, g[sc_name + ".weight"], g[sc_name + ".bias"], up=1)
                     ops.conv(dy, None, p[sc_name + ".weight"], transposed=True, cout0=C0, out0=u0, out1=u1, accumulate=True)
-                else:
-                    ops.add(u0, dy, out=u0)
+                else:       # identity shortcut: dL/d(upsampled input) += dy, channel by channel over the two sources
+                    ops.conv(dy, None, self._eye(dy.shape[1]), transposed=True, cout0=C0, out0=u0, out1=u1, accumulate=True)
                 d0 = ops.upsample2_bwd(u0)
                 d1 = ops.upsample2_bwd(u1) if u1 is not None else None
             dcvt, dprev = (d1, d0) if i > 0 else (d0, None)
@@ -159,13 +158,17 @@ class DecoderTrainer:
             ops.adam(p[name], g[name], self.m[name], self.v[name], lr_t, self.b1, self.b2, self.eps, rescale=1.0 / (n * world), wd=self.wd)
         return float(loss.cpu().numpy().mean())
 
-    def _identity_up_add(self, x, y):
-        """y + nearest-x2(x) without a dedicated kernel: a 1x1 convolution with the identity matrix on the
-        upsampled read (only level 0 of the reference's decoder: 32 -> 32 channels at 4x4 -> 8x8)."""
-        C = x.shape[1]
-        eye = torch.eye(C, device=self.dev).reshape(C, C, 1, 1).contiguous()
+    def _eye(self, C):
+        e = self._eyes.get(C)
+        if e is None:
+            e = self._eyes[C] = torch.eye(C, device=self.dev).reshape(C, C, 1, 1).contiguous()
+        return e
+
+    def _identity_up_add(self, x0, x1, y):
+        """y + nearest-x2(concat(x0, x1)) without a dedicated kernel: a 1x1 convolution with the identity matrix on the
+        upsampled read (level 0 of the reference's decoder: 32 -> 32 channels at 4x4 -> 8x8; x1 is None there)."""
         out = y.clone()
-        ops.conv(x, None, eye, None, up=1, out0=out, accumulate=True)
+        ops.conv(x0, x1, self._eye(y.shape[1]), None, up=1, out0=out, accumulate=True)
         return out
 
     # -- parameters -------------------------------------------------------------------------------

@@ -287,3 +287,26 @@ def test_pair_gatherer_over_rccl_single_rank(torch_cuda, tmp_path):
     script.write_text(_RCCL_WORKER)
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "RCCL_GATHER_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("fmap_max,dec_features,classes,batch", [(48, [48, 32, 48, 80, 16, 48], 2, 3), (96, [16, 96, 32, 80, 48, 16], 3, 2), (48, [32, 16, 32, 64, 128, 16], 2, 2)])
+def test_odd_channel_counts_bit_exact(torch_cuda, oracle_lib, fmap_max, dec_features, classes, batch):
+    """Channel counts that are multiples of 16 but not powers of two (3 or 6 output-channel groups, 5 channel
+    blocks), a 3-class decoder and identity / 1x1 shortcuts in unusual places: every kernel selection path
+    (tile geometry, channel tile, resident / streamed weights) must still reproduce the oracle bit for bit."""
+    from gan_segmentation_amd import weights as W
+    gcfg = W.generator_config(max_res_log2=7, fmap_base=3072, fmap_max=fmap_max)
+    chans = W.generator_channels(gcfg)
+    assert all(c % 16 == 0 for c in chans), chans
+    dcfg = W.decoder_config(7, num_classes=classes, in_channels=chans)
+    dcfg["features"] = list(dec_features) + [classes]
+    gp = W.synthetic_generator_params(gcfg, seed=11, trivial_norm=False)
+    dp = W.synthetic_decoder_params(dcfg, seed=12)
+    z, noise = W.synthetic_inputs(gcfg, batch)
+    gen = _build(gcfg, gp, dcfg, dp, batch)
+    img, mask = gen.generate_batch(z, noise)
+    o = oracle_lib.Oracle(gcfg, gp, dcfg, dp)
+    img_o, mask_o = o.generate(z, noise)
+    assert_same(img.cpu().numpy(), img_o, "image")
+    assert_same(mask.cpu().numpy(), mask_o, "mask")
+    assert mask_o.max() <= classes - 1

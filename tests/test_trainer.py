@@ -52,8 +52,10 @@ def test_two_training_steps_match_autograd():
     assert not np.array_equal(tr.state_dict()["cvt_block_0.0.weight"], dp["cvt_block_0.0.weight"])
 
 
-def test_gradients_match_autograd_directly():
-    """The raw gradients (before Adam's normalisation hides their scale)."""
+@pytest.mark.parametrize("features", [None, [32, 16, 32, 64, 2]])
+def test_gradients_match_autograd_directly(features):
+    """The raw gradients (before Adam's normalisation hides their scale).  The second decoder has identity
+    shortcuts over a concatenated input (2 * features[i] == features[i+1]) and a 1x1 shortcut at level 0."""
     import torch
     from gan_segmentation_amd import weights as W
     from gan_segmentation_amd.trainer import DecoderTrainer
@@ -62,6 +64,8 @@ def test_gradients_match_autograd_directly():
     gcfg = W.reduced_generator_config(mr)
     chans = W.generator_channels(gcfg)
     dcfg = W.decoder_config(mr, in_channels=chans)
+    if features is not None:
+        dcfg["features"] = list(features)
     dp = W.synthetic_decoder_params(dcfg, seed=6)
     rng = np.random.default_rng(1)
     feats = [rng.standard_normal((1, c, 4 << i, 4 << i)).astype(np.float32) for i, c in enumerate(chans)]
