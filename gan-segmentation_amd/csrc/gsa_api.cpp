@@ -91,7 +91,7 @@ struct gsa_ctx {
 
     // decoder
     bool d_init = false, d_ready = false;
-    int d_n = 0, d_bn = 1;
+    int d_n = 0, d_s0 = 0, d_bn = 1;
     int d_feat[kMaxLevels + 1] = {0}, d_inch[kMaxLevels] = {0};
     std::map<std::string, HostTensor> dparams;
     DecLevelDev dl[kMaxLevels];
@@ -643,8 +643,10 @@ int gsa_generator_commit(gsa_ctx* c) {
 int gsa_decoder_init(gsa_ctx* c, const gsa_decoder_config* d) {
     if (!c || !d || !d->features || !d->in_channels) return GSA_ERR_INVALID;
     if (d->num_feats < 1 || d->num_feats > kMaxLevels) return fail(c, GSA_ERR_INVALID, "num_feats %d out of range", d->num_feats);
-    if (d->start_res != 0) return fail(c, GSA_ERR_INVALID, "start_res != 0 is not supported");
+    // start_res: the first feature the decoder consumes (reference networks_seg.py:56,64,81,102)
+    if (d->start_res < 0 || d->start_res >= d->num_feats) return fail(c, GSA_ERR_INVALID, "start_res %d not in 0..%d", d->start_res, d->num_feats - 1);
     c->d_n = d->num_feats;
+    c->d_s0 = d->start_res;
     c->d_bn = d->use_bn;
     for (int i = 0; i <= d->num_feats; ++i) c->d_feat[i] = d->features[i];
     for (int i = 0; i < d->num_feats; ++i) {
@@ -698,11 +700,11 @@ int gsa_decoder_commit(gsa_ctx* c) {
     c->d_ready = false;
     free_all(c->d_allocs);
     auto& T = c->d_allocs;
-    for (int i = 0; i < n; ++i) {
+    for (int i = c->d_s0; i < n; ++i) {
         DecLevelDev& d = c->dl[i];
         d.F = c->d_feat[i]; d.I = c->d_inch[i];
         d.cs = c->d_feat[i + 1];
-        d.in_c = d.F * (i > 0 ? 2 : 1);
+        d.in_c = d.F * (i > c->d_s0 ? 2 : 1);
         d.is_last = i == n - 1;
         snprintf(nm, sizeof nm, "cvt_block_%d.0", i);
         NEED(P, std::string(nm) + ".weight", (size_t)d.F * d.I * 9, &w);
@@ -798,7 +800,7 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
         HIP_TRY(hipMemset(c->stamps, 0, 16 * sizeof(unsigned long long)));
     }
     if (c->d_ready) {
-        for (int i = 0; i < c->d_n; ++i) {
+        for (int i = c->d_s0; i < c->d_n; ++i) {
             const DecLevelDev& d = c->dl[i];
             const size_t R = (size_t)4 << i;
             if (int rc = dev_alloc(c, N * R * R * d.I, &c->din[i], T)) return rc;
@@ -918,7 +920,8 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
     const int nl = i_end < 0 ? c->d_n : i_end;
     const double N = n;
     char layer[64];
-    for (int i = i_begin; i < nl; ++i) {
+    const int s0 = c->d_s0;   // levels below start_res have no blocks
+    for (int i = std::max(i_begin, s0); i < nl; ++i) {
         const DecLevelDev& d = c->dl[i];
         const int R = 4 << i;
         const double px = N * R * R;
@@ -938,7 +941,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             const double px2 = 4 * px;
             {   // ResBlock conv a (+ fused 1x1 shortcut) on nearest-x2(concat(prev, cvt))
                 ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
-                if (i > 0) { cp.src0 = c->prev[i - 1]; cp.C0 = d.F; cp.src1 = c->cvt[i]; cp.C1 = d.F; }
+                if (i > s0) { cp.src0 = c->prev[i - 1]; cp.C0 = d.F; cp.src1 = c->cvt[i]; cp.C1 = d.F; }
                 else { cp.src0 = c->cvt[i]; cp.C0 = d.F; }
                 cp.Hs = R; cp.Ws = R; cp.up = 1; cp.H = R2; cp.W = R2;
                 cp.wpk = d.a_w; cp.Cout = d.cs; cp.out = c->ya[i];
@@ -965,7 +968,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 cp.wpk = d.b_w; cp.Cout = d.cs; cp.out = c->prev[i];
                 cp.bias = d.b_b; cp.bn_s = d.b_s; cp.bn_rm = d.b_rm; cp.bn_beta = d.b_beta;
                 if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = R2 >= 16 ? 1 : 0; }   // sub-pixel conv a stores the shortcut at input resolution
-                else if (i == 0) { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
+                else if (i == s0) { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 else { cp.resid = c->prev[i - 1]; cp.resid1 = c->cvt[i]; cp.res_c0 = d.F; cp.resid_up = 1; }   // ... over concat(prev, cvt)
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
                 Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
@@ -974,7 +977,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
         } else {
             snprintf(layer, sizeof layer, "d.final_%d", i);
             Launch lp(c, s, "final_conv_kernel", layer, 2.0 * px * d.cs * d.in_c * 9, px * (4.0 * d.in_c + (logits ? 4.0 * d.cs : 0) + (mask ? 1 : 0)));
-            HIP_TRY(launch_final_conv(c->prev[i - 1], d.F, c->cvt[i], d.F, d.f_w, d.f_b, logits, mask, n, R, R, d.cs, s));
+            HIP_TRY(launch_final_conv(i > s0 ? c->prev[i - 1] : nullptr, i > s0 ? d.F : 0, c->cvt[i], d.F, d.f_w, d.f_b, logits, mask, n, R, R, d.cs, s));
         }
     }
     return GSA_OK;
@@ -1004,7 +1007,7 @@ int gsa_decoder_forward(gsa_ctx* c, void* stream, int32_t n, const float* const*
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const float* fsrc[kMaxLevels];
-    for (int i = 0; i < c->d_n; ++i) {
+    for (int i = c->d_s0; i < c->d_n; ++i) {   // entries below start_res are not read (they may be null)
         if (!feats[i]) return fail(c, GSA_ERR_INVALID, "feature %d is null", i);
         const int R = 4 << i;
         Launch lp(c, s, "import_nhwc_kernel", "d.import", 0.0, 8.0 * n * R * R * c->dl[i].I);

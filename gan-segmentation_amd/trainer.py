@@ -25,12 +25,13 @@ class DecoderTrainer:
     def __init__(self, cfg, params, device=0, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, seed=1,
                  dropout_keep=0.5):
         require_gpu()
-        if cfg["start_res"] != 0 or not cfg["use_bn"]:
-            raise NotImplementedError("training supports the reference's configuration: start_res=0, use_bn=True")
+        if not cfg["use_bn"]:
+            raise NotImplementedError("training supports the reference's configuration: use_bn=True")
         self.cfg = dict(cfg)
         self.dev = torch.device("cuda", device)
         self.F, self.I = list(cfg["features"]), list(cfg["in_channels"])
         self.n_levels = len(self.I)
+        self.s0 = int(cfg["start_res"])     # first feature consumed (reference networks_seg.py:56)
         self.lr, self.b1, self.b2, self.eps, self.wd = lr, beta1, beta2, eps, wd
         self.seed = seed
         self.keep = dropout_keep if cfg.get("use_dropout", True) else 1.0
@@ -68,7 +69,7 @@ class DecoderTrainer:
     def step(self, features, labels, masks=None):
         """features: list of (n,C_i,R_i,R_i) fp32 arrays/tensors; labels (n,H,W) integers, -1 = ignore.
         ``masks``: explicit dropout keep masks (tests); default: counter-based.  -> mean loss of the batch."""
-        p, g, F, nl = self.p, self.g, self.F, self.n_levels
+        p, g, F, nl, s0 = self.p, self.g, self.F, self.n_levels, self.s0
         feats = [torch.as_tensor(np.asarray(f) if not torch.is_tensor(f) else f, dtype=torch.float32).to(self.dev).contiguous()
                  for f in features]
         if feats[0].dim() == 3:
@@ -83,14 +84,14 @@ class DecoderTrainer:
         self.t += 1
 
         # ---- forward (training mode), keeping what the backward pass needs
-        saved = []
+        saved = {}
         prev = None
         logits = None
-        for i in range(nl):
+        for i in range(s0, nl):
             cv = "cvt_block_%d" % i
             cv_raw, _ = ops.conv(feats[i], None, p[cv + ".0.weight"], p[cv + ".0.bias"])
             cvt, cv_stats = self._bn_fwd(cv + ".1", cv_raw, masks[i])
-            src0, src1 = (prev, cvt) if i > 0 else (cvt, None)
+            src0, src1 = (prev, cvt) if i > s0 else (cvt, None)
             rec = {"cv_raw": cv_raw, "cv_stats": cv_stats, "src0": src0, "src1": src1}
             if i < nl - 1:
                 b = "main_block_%d.1.base_layers" % i
@@ -108,13 +109,13 @@ class DecoderTrainer:
             else:
                 fn = "main_block_%d.0" % i
                 logits, _ = ops.conv(src0, src1, p[fn + ".weight"], p[fn + ".bias"])
-            saved.append(rec)
+            saved[i] = rec
 
         loss, dlogits = ops.softmax_ce(logits, lab)
 
         # ---- backward
         dprev = None        # gradient w.r.t. the output of main block i-1 (`prev` of level i)
-        for i in reversed(range(nl)):
+        for i in reversed(range(s0, nl)):
             rec = saved[i]
             src0, src1 = rec["src0"], rec["src1"]
             C0 = src0.shape[1]
@@ -139,7 +140,7 @@ class DecoderTrainer:
                     ops.conv(dy, None, self._eye(dy.shape[1]), transposed=True, cout0=C0, out0=u0, out1=u1, accumulate=True)
                 d0 = ops.upsample2_bwd(u0)
                 d1 = ops.upsample2_bwd(u1) if u1 is not None else None
-            dcvt, dprev = (d1, d0) if i > 0 else (d0, None)
+            dcvt, dprev = (d1, d0) if i > s0 else (d0, None)
             cv = "cvt_block_%d" % i
             gv = self._bn_bwd(cv + ".1", rec["cv_raw"], rec["cv_stats"], dcvt, masks[i])
             ops.conv_wgrad(feats[i], None, gv, 3, g[cv + ".0.weight"], g[cv + ".0.bias"])

@@ -55,7 +55,7 @@ typedef struct {
 /* Decoder(cfg): reference networks_seg.py:51-62, seg_solver.py:119-128. */
 typedef struct {
     int32_t num_feats;            /* len(in_channels) */
-    int32_t start_res;            /* 0 */
+    int32_t start_res;            /* first feature consumed, 0..num_feats-1 (networks_seg.py:56; the reference sets 0) */
     int32_t use_bn;               /* 1 */
     const int32_t* features;      /* host, num_feats+1 entries; last = num_classes */
     const int32_t* in_channels;   /* host, num_feats entries */

@@ -744,7 +744,9 @@ GSAO_API int gsao_decoder_init(gsao_ctx* c, const gsa_decoder_config* d) {
         c->d_inch[i] = d->in_channels[i];
         if (c->d_inch[i] % 16 || c->d_feat[i] % 16) return fail(c, GSA_ERR_INVALID, "decoder channels must be multiples of 16%s (%ld)", "", i);
     }
-    if (d->start_res != 0) return fail(c, GSA_ERR_INVALID, "start_res != 0 is not supported%s (%ld)", "", d->start_res);
+    /* start_res: the first feature the decoder consumes (reference networks_seg.py:56,64,81,102); levels below it
+     * have no blocks and their features are ignored */
+    if (d->start_res < 0 || d->start_res >= d->num_feats) return fail(c, GSA_ERR_INVALID, "start_res out of range%s (%ld)", "", d->start_res);
     c->d_init = 1;
     return GSA_OK;
 }
@@ -782,7 +784,7 @@ GSAO_API int gsao_decoder_commit(gsao_ctx* c) {
     char nm[128], pf[96];
     float *w, *b;
     const int n = c->d_n;
-    for (int i = 0; i < n; ++i) {
+    for (int i = c->d_s0; i < n; ++i) {
         dec_level* d = &c->dl[i];
         d->F = c->d_feat[i]; d->I = c->d_inch[i];
         snprintf(nm, sizeof nm, "cvt_block_%d.0.weight", i); NEED(t, nm, (int64_t)d->F * d->I * 9, &w);
@@ -791,7 +793,7 @@ GSAO_API int gsao_decoder_commit(gsao_ctx* c) {
         snprintf(pf, sizeof pf, "cvt_block_%d.1", i);
         { int rc = load_bn(c, pf, d->F, &d->cvt_s, &d->cvt_rm, &d->cvt_beta); if (rc) return rc; }
         d->cs = c->d_feat[i + 1];
-        d->in_c = d->F * (i > 0 ? 2 : 1);
+        d->in_c = d->F * (i > c->d_s0 ? 2 : 1);
         d->is_last = i == n - 1;
         if (!d->is_last) {
             const int second = c->d_bn ? 3 : 2;
@@ -839,7 +841,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
     const int nl = c->d_n;
     /* feature i is at 4*2^i pixels (the generator's 4..2^max ladder, reference networks_stylegan.py:184-192) */
     size_t maxbuf = 0;
-    for (int i = 0; i < nl; ++i) {
+    for (int i = c->d_s0; i < nl; ++i) {
         const size_t R = (size_t)4 << i;
         size_t a = R * R * (size_t)c->dl[i].I;
         size_t b2 = 4 * R * R * (size_t)(c->dl[i].cs > c->dl[i].in_c ? c->dl[i].cs : c->dl[i].in_c);
@@ -853,7 +855,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
     float* prev = (float*)malloc(sizeof(float) * maxbuf);
     if (!fin || !cat || !ya || !yb || !prev) return fail(c, GSA_ERR_NOMEM, "out of memory in decoder_forward%s (%ld)", "", 0);
     for (int s = 0; s < n; ++s) {
-        for (int i = 0; i < nl; ++i) {
+        for (int i = c->d_s0; i < nl; ++i) {
             const dec_level* d = &c->dl[i];
             const int R = 4 << i;
             const size_t npix = (size_t)R * R;
@@ -862,7 +864,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
             conv3x3(fin, R, R, d->I, 0, d->cvt_w, d->F, ya, c->bf16);
             bias_bn_act(ya, npix, d->F, d->cvt_b, d->cvt_s, d->cvt_rm, d->cvt_beta);
             /* concat(prev, cvt) on channels, reference :108-109 */
-            if (i > 0) {
+            if (i > c->d_s0) {
                 for (size_t p = 0; p < npix; ++p) {
                     memcpy(cat + p * d->in_c, prev + p * d->F, sizeof(float) * d->F);
                     memcpy(cat + p * d->in_c + d->F, ya + p * d->F, sizeof(float) * d->F);

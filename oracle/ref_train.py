@@ -21,16 +21,16 @@ def _bn_lrelu(x, p, prefix, running, momentum=0.9):
 
 def forward_train(cfg, p, feats, masks, keep=0.5):
     """-> (logits, {new running statistics})."""
-    nl = len(cfg["in_channels"])
+    nl, s0 = len(cfg["in_channels"]), cfg["start_res"]
     running = {}
     prev = None
-    for i in range(nl):
+    for i in range(s0, nl):
         cv = "cvt_block_%d" % i
         x = F.conv2d(feats[i], p[cv + ".0.weight"], p[cv + ".0.bias"], padding=1)
         x = _bn_lrelu(x, p, cv + ".1", running)
         if masks[i] is not None:
             x = x * masks[i].float() / keep
-        inp = torch.cat([prev, x], 1) if i > 0 else x
+        inp = torch.cat([prev, x], 1) if i > s0 else x
         if i < nl - 1:
             b = "main_block_%d.1.base_layers" % i
             up = F.interpolate(inp, scale_factor=2, mode="nearest")

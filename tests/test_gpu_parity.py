@@ -310,3 +310,30 @@ def test_odd_channel_counts_bit_exact(torch_cuda, oracle_lib, fmap_max, dec_feat
     assert_same(img.cpu().numpy(), img_o, "image")
     assert_same(mask.cpu().numpy(), mask_o, "mask")
     assert mask_o.max() <= classes - 1
+
+
+@pytest.mark.parametrize("start_res", [2, 5])
+def test_decoder_start_res_bit_exact(torch_cuda, oracle_lib, start_res):
+    """cfg['start_res'] (reference networks_seg.py:56,64,81,102): levels below it have no blocks, the first consumed
+    feature is not concatenated; 5 = the final level alone.  The fused generate path and the decoder entry alone."""
+    from gan_segmentation_amd import weights as W
+    from gan_segmentation_amd.networks_seg import Decoder
+    gcfg = W.reduced_generator_config(7)
+    gp = W.synthetic_generator_params(gcfg, seed=2, trivial_norm=False)
+    dcfg = W.decoder_config(7, in_channels=W.generator_channels(gcfg))
+    dcfg["start_res"] = start_res
+    dp = W.synthetic_decoder_params(dcfg, seed=3)
+    z, noise = W.synthetic_inputs(gcfg, 2)
+    gen = _build(gcfg, gp, dcfg, dp, 2)
+    img, mask = gen.generate_batch(z, noise)
+    o = oracle_lib.Oracle(gcfg, gp, dcfg, dp)
+    img_o, mask_o = o.generate(z, noise)
+    assert_same(img.cpu().numpy(), img_o, "image")
+    assert_same(mask.cpu().numpy(), mask_o, "mask")
+    _rgb, _img, feats = o.generator(z, noise)
+    logits_o, mask_o2 = o.decoder(feats)
+    dec = Decoder(dcfg, 1)
+    dec.load_parameters(dp)
+    logits, mask2 = dec(*feats, want_mask=True)
+    assert_same(logits.cpu().numpy(), logits_o, "logits")
+    assert_same(mask2.cpu().numpy(), mask_o2, "mask (decoder entry)")

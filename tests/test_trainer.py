@@ -52,10 +52,11 @@ def test_two_training_steps_match_autograd():
     assert not np.array_equal(tr.state_dict()["cvt_block_0.0.weight"], dp["cvt_block_0.0.weight"])
 
 
-@pytest.mark.parametrize("features", [None, [32, 16, 32, 64, 2]])
-def test_gradients_match_autograd_directly(features):
+@pytest.mark.parametrize("features,start_res", [(None, 0), ([32, 16, 32, 64, 2], 0), (None, 2)])
+def test_gradients_match_autograd_directly(features, start_res):
     """The raw gradients (before Adam's normalisation hides their scale).  The second decoder has identity
-    shortcuts over a concatenated input (2 * features[i] == features[i+1]) and a 1x1 shortcut at level 0."""
+    shortcuts over a concatenated input (2 * features[i] == features[i+1]) and a 1x1 shortcut at level 0; the
+    third starts at feature 2 (cfg['start_res'], reference networks_seg.py:56): the lower levels have no blocks."""
     import torch
     from gan_segmentation_amd import weights as W
     from gan_segmentation_amd.trainer import DecoderTrainer
@@ -66,7 +67,9 @@ def test_gradients_match_autograd_directly(features):
     dcfg = W.decoder_config(mr, in_channels=chans)
     if features is not None:
         dcfg["features"] = list(features)
+    dcfg["start_res"] = start_res
     dp = W.synthetic_decoder_params(dcfg, seed=6)
+    assert ("cvt_block_0.0.weight" in dp) == (start_res == 0)
     rng = np.random.default_rng(1)
     feats = [rng.standard_normal((1, c, 4 << i, 4 << i)).astype(np.float32) for i, c in enumerate(chans)]
     R = 4 << (len(chans) - 1)
