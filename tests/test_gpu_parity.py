@@ -312,8 +312,8 @@ def test_odd_channel_counts_bit_exact(torch_cuda, oracle_lib, fmap_max, dec_feat
     assert mask_o.max() <= classes - 1
 
 
-@pytest.mark.parametrize("start_res", [2, 5])
-def test_decoder_start_res_bit_exact(torch_cuda, oracle_lib, start_res):
+@pytest.mark.parametrize("start_res,use_bn", [(2, True), (5, True), (0, False), (1, False)])
+def test_decoder_start_res_bit_exact(torch_cuda, oracle_lib, start_res, use_bn):
     """cfg['start_res'] (reference networks_seg.py:56,64,81,102): levels below it have no blocks, the first consumed
     feature is not concatenated; 5 = the final level alone.  The fused generate path and the decoder entry alone."""
     from gan_segmentation_amd import weights as W
@@ -321,7 +321,7 @@ def test_decoder_start_res_bit_exact(torch_cuda, oracle_lib, start_res):
     gcfg = W.reduced_generator_config(7)
     gp = W.synthetic_generator_params(gcfg, seed=2, trivial_norm=False)
     dcfg = W.decoder_config(7, in_channels=W.generator_channels(gcfg))
-    dcfg["start_res"] = start_res
+    dcfg["start_res"], dcfg["use_bn"] = start_res, use_bn   # use_bn=False: no BatchNorm layers (networks_seg.py:20-33)
     dp = W.synthetic_decoder_params(dcfg, seed=3)
     z, noise = W.synthetic_inputs(gcfg, 2)
     gen = _build(gcfg, gp, dcfg, dp, 2)
