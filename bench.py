@@ -24,6 +24,7 @@ MB_PER_SAMPLE = {"ffhq": 1440.0, "cars": 623.2, "bedrooms": 234.4}
 PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (the headline figure with 2:1 sparsity is not used)
 PEAK_HBM_GBS = 8000.0
+MEASURED_HBM_GBS = 6290.0   # copy bandwidth this part reaches (MI355X_MICROARCH.md, HBM section)
 
 
 def pmc_traffic(kernel_name):
@@ -238,6 +239,7 @@ def main():
                                            (PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS), 4),
                 "algorithmic_hbm_gbs": round(MB_PER_SAMPLE[args.gan] * value / 1e3, 1),
                 "hbm_frac_of_peak": round(MB_PER_SAMPLE[args.gan] * value / 1e3 / world / PEAK_HBM_GBS, 4),
+                "hbm_frac_of_measured_peak": round(MB_PER_SAMPLE[args.gan] * value / 1e3 / world / MEASURED_HBM_GBS, 4),
                 "kernel_ms_per_step": round(kms / args.steps, 3),
             },
             "kernels": [{"name": e["name"], "ms_per_step": round(e["ms"] / args.steps, 3),

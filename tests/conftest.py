@@ -17,3 +17,20 @@ def oracle_lib():
     from oracle import binding
     binding.build()
     return binding
+
+
+@pytest.fixture(scope="session")
+def hip_library():
+    """Path of the built HIP library (built here if missing; hipcc cross-compiles without a GPU)."""
+    import subprocess
+    from gan_segmentation_amd import _lib
+    if not os.path.exists(_lib.HIP_LIBRARY):
+        subprocess.check_call([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT)
+    return _lib.HIP_LIBRARY
+
+
+@pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
