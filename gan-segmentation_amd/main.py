@@ -52,7 +52,8 @@ def generate(cfg, limit=None, workers=None):
     index = lo
     # the writer copies each batch out through pinned buffers and encodes it on a thread pool while the
     # GPU already computes the next one
-    with DatasetWriter(dst_dir, workers=workers) as writer:
+    # additive key JPEG_ON_GPU (default on): the image files are encoded by the HIP baseline-JPEG kernels
+    with DatasetWriter(dst_dir, workers=workers, gpu_jpeg=bool(cfg.get("JPEG_ON_GPU", True))) as writer:
         while index < hi:
             bs = min(batch, hi - index)
             # latents and noise keyed on the global sample index: the files are the same for any number of ranks

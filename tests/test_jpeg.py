@@ -122,3 +122,29 @@ def test_hip_encoder_reports_a_short_buffer(torch_cuda):
     need = len(J.encode(img[0], 100, 2)) - len(enc.header)
     assert int(lengths.cpu()[0]) == -need
     assert enc.files(torch.from_numpy(img).cuda())[0] == J.encode(img[0], 100, 2)      # retried with the worst-case stride
+
+
+@pytest.mark.gpu
+def test_dataset_writer_with_gpu_jpeg(torch_cuda, tmp_path):
+    """DatasetWriter(gpu_jpeg=True): the files `main.py generate` writes -- names as reference main.py:100-103, the
+    JPEG decodes to exactly what libjpeg-turbo (cv2) stores for the same pixels, the PNG holds the class indices."""
+    import torch
+    from PIL import Image
+    from gan_segmentation_amd.dataset_writer import DatasetWriter
+    rng = np.random.default_rng(5)
+    n, R = 11, 128
+    pics = images(rng, R, R)
+    img = np.stack([pics[k] for k in ("smooth", "noise", "stripes", "black", "white", "smooth", "smooth", "noise", "stripes", "smooth", "noise")])
+    mask = (rng.random((n, R, R)) > 0.5).astype(np.uint8)
+    dimg, dmask = torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda()
+    with DatasetWriter(str(tmp_path), workers=4, gpu_jpeg=True) as w:
+        w.submit(dimg[:4], dmask[:4], 0)
+        w.submit(dimg[4:8], dmask[4:8], 4)
+        w.submit(dimg[8:], dmask[8:], 8)       # a short last batch
+    assert w.written == n
+    assert sorted(os.listdir(tmp_path)) == sorted(["img_%06d.jpg" % i for i in range(n)] + ["mask_%06d.png" % i for i in range(n)])
+    for i in range(n):
+        got = np.asarray(Image.open(tmp_path / ("img_%06d.jpg" % i)).convert("RGB"))
+        ref = np.asarray(Image.open(io.BytesIO(pillow_bytes(img[i], 95, 0))).convert("RGB"))
+        assert np.array_equal(got, ref), i
+        assert np.array_equal(np.asarray(Image.open(tmp_path / ("mask_%06d.png" % i))), mask[i])
