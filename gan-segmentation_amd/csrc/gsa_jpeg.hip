@@ -216,54 +216,68 @@ struct BitSink {
     }
 };
 
+// One 8x8 block: 64 zigzag-ordered coefficients held in registers (8 x 16 bytes).
+__device__ __forceinline__ void encode_block(BitSink& o, const uint4 (&u)[8], int& pred, const uint32_t* dc, const uint32_t* ac) {
+    int run = 0;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        const uint32_t w[4] = {u[ch].x, u[ch].y, u[ch].z, u[ch].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int v = (int)(int16_t)(w[j >> 1] >> ((j & 1) * 16));
+            if (ch == 0 && j == 0) {                     // DC: difference to the previous block of the component
+                const int diff = v - pred;
+                pred = v;
+                const int a = diff < 0 ? -diff : diff;
+                const int nb = 32 - __clz(a);
+                const uint32_t e = dc[nb];
+                const unsigned vb = (unsigned)(diff < 0 ? diff - 1 : diff) & ((1u << nb) - 1u);
+                o.put(((e >> 5) << nb) | vb, (int)(e & 31u) + nb);
+            } else if (v == 0) {
+                ++run;
+            } else {
+                while (run > 15) { const uint32_t z = ac[0xF0]; o.put(z >> 5, (int)(z & 31u)); run -= 16; }
+                const int a = v < 0 ? -v : v;
+                const int nb = 32 - __clz(a);
+                const uint32_t e = ac[(run << 4) + nb];
+                const unsigned vb = (unsigned)(v < 0 ? v - 1 : v) & ((1u << nb) - 1u);
+                o.put(((e >> 5) << nb) | vb, (int)(e & 31u) + nb);
+                run = 0;
+            }
+        }
+    }
+    if (run) { const uint32_t e = ac[0]; o.put(e >> 5, (int)(e & 31u)); }   // end of block
+}
+
 // One lane per restart interval (`restart` MCUs): sequential Huffman coding of its blocks into scratch + t*segcap.
+// The lane is latency-bound (a wave per CU at most): the 128 bytes of a block are fetched with eight independent
+// 16-byte loads, the next block's while the current one is coded, and the code tables sit in LDS.
 __global__ __launch_bounds__(64) void jpeg_entropy_kernel(const int16_t* __restrict__ coef, int mcus_per_img, int restart,
                                                           int segs_per_img, int total_segs, int segcap,
                                                           uint8_t* __restrict__ scratch, int* __restrict__ seglen) {
+    __shared__ uint32_t huff[4][256];
+    for (int i = threadIdx.x; i < 1024; i += 64) huff[i >> 8][i & 255] = kHuffDev[i >> 8].e[i & 255];
+    __syncthreads();
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t >= total_segs) return;
     const int img = t / segs_per_img, s = t - img * segs_per_img;
     const int m0 = s * restart, m1 = min(m0 + restart, mcus_per_img);
     BitSink o{scratch + (size_t)t * segcap, 0, 0ull, 0};
     int pred[3] = {0, 0, 0};
-    for (int m = m0; m < m1; ++m) {
-#pragma unroll 1
-        for (int b = 0; b < 6; ++b) {
-            const uint4* c = reinterpret_cast<const uint4*>(coef + ((size_t)((size_t)img * mcus_per_img + m) * 6 + b) * 64);
-            const int ci = b < 4 ? 0 : b - 3;
-            const uint32_t* dc = kHuffDev[b < 4 ? 0 : 2].e;
-            const uint32_t* ac = kHuffDev[b < 4 ? 1 : 3].e;
-            int run = 0;
-#pragma unroll 1
-            for (int ch = 0; ch < 8; ++ch) {
-                const uint4 u = c[ch];
-                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    const uint4* c = reinterpret_cast<const uint4*>(coef + ((size_t)img * mcus_per_img + m0) * 384);   // 8 x uint4 per block
+    const int nblocks = (m1 - m0) * 6;
+    uint4 cur[8], nxt[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    int v = (int)(int16_t)(w[j >> 1] >> ((j & 1) * 16));
-                    if (ch == 0 && j == 0) {                     // DC: difference to the previous block of the component
-                        const int diff = v - pred[ci];
-                        pred[ci] = v;
-                        const int a = diff < 0 ? -diff : diff;
-                        const int nb = 32 - __clz(a);
-                        const uint32_t e = dc[nb];
-                        const unsigned vb = (unsigned)(diff < 0 ? diff - 1 : diff) & ((1u << nb) - 1u);
-                        o.put(((e >> 5) << nb) | vb, (int)(e & 31u) + nb);
-                    } else if (v == 0) {
-                        ++run;
-                    } else {
-                        while (run > 15) { const uint32_t z = ac[0xF0]; o.put(z >> 5, (int)(z & 31u)); run -= 16; }
-                        const int a = v < 0 ? -v : v;
-                        const int nb = 32 - __clz(a);
-                        const uint32_t e = ac[(run << 4) + nb];
-                        const unsigned vb = (unsigned)(v < 0 ? v - 1 : v) & ((1u << nb) - 1u);
-                        o.put(((e >> 5) << nb) | vb, (int)(e & 31u) + nb);
-                        run = 0;
-                    }
-                }
-            }
-            if (run) { const uint32_t e = ac[0]; o.put(e >> 5, (int)(e & 31u)); }   // end of block
-        }
+    for (int k = 0; k < 8; ++k) cur[k] = c[k];
+    for (int bi = 0; bi < nblocks; ++bi) {
+        const int pf = bi + 1 < nblocks ? bi + 1 : bi;          // unconditional (clamped) prefetch of the next block
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nxt[k] = c[pf * 8 + k];
+        const int b = bi % 6;
+        if (b < 4) encode_block(o, cur, pred[0], huff[0], huff[1]);
+        else encode_block(o, cur, pred[b - 3], huff[2], huff[3]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
     }
     if (o.nbits) o.put((1u << (8 - o.nbits)) - 1u, 8 - o.nbits);   // pad the last byte with ones
     if (s != segs_per_img - 1) {                                    // RSTm in front of the next interval
@@ -277,25 +291,25 @@ __global__ __launch_bounds__(64) void jpeg_entropy_kernel(const int16_t* __restr
 __global__ __launch_bounds__(256) void jpeg_offsets_kernel(const int* __restrict__ seglen, int segs_per_img,
                                                            int* __restrict__ segoff, int* __restrict__ lengths,
                                                            uint8_t* __restrict__ out, long long out_stride) {
-    __shared__ int part[256];
-    __shared__ int carry;
-    const int img = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
+    __shared__ int wsum[4];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = 0;                                      // same value in every thread
     for (int base = 0; base < segs_per_img; base += 256) {
         const int i = base + tid;
         const int v = i < segs_per_img ? seglen[(size_t)img * segs_per_img + i] : 0;
-        part[tid] = v;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {   // Hillis-Steele inclusive scan
-            const int add = tid >= d ? part[tid - d] : 0;
-            __syncthreads();
-            part[tid] += add;
-            __syncthreads();
+        int incl = v;                                   // inclusive scan inside the wave by shuffles
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
         }
-        if (i < segs_per_img) segoff[(size_t)img * segs_per_img + i] = carry + part[tid] - v;
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        if (tid == 0) carry += part[255];
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { before += w < wave ? wsum[w] : 0; total += wsum[w]; }
+        if (i < segs_per_img) segoff[(size_t)img * segs_per_img + i] = carry + before + incl - v;
+        carry += total;
         __syncthreads();
     }
     if (tid == 0) {

@@ -164,6 +164,103 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     if (a.db && c0 == 0 && o0 + o < a.Cout) atomicAdd(&a.db[o0 + o], bsum);
 }
 
+// Weight gradient on the matrix cores (v_mfma_f32_16x16x4_f32), straight from the NCHW tensors: dW[o][c][tap] is a
+// GEMM with M = 16 output channels, N = 16 input channels, K = pixels, and in NCHW both operands are contiguous along K.
+// A lane (m = lane & 15, q = lane >> 4) loads 4 consecutive pixels of dy[o0+m] and of the tap-shifted x[c0+m] (one
+// aligned 16-byte load per input row plus the two neighbours for the horizontal taps); MFMA j multiplies element j of
+// both, so the four MFMAs of a 16-pixel chunk cover pixels {4q+j} -- a permutation of K, which a sum does not see.
+// A wave keeps the K*K 16x16 accumulators in registers over its share of 64-pixel row segments; the four waves of a
+// block are added in LDS and each block issues one float atomic per weight.  W must be a multiple of 16.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int K>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
+    constexpr int P = K / 2, KK = K * K;
+    __shared__ float red[4][KK * 4 * 64];
+    const int Cin = a.C0 + a.C1, ncb = (Cin + 15) / 16;
+    const int o0 = (blockIdx.y / ncb) * 16, c0 = (blockIdx.y % ncb) * 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m = lane & 15, q = lane >> 4;
+    const int o = o0 + m, c = c0 + m;
+    const bool o_ok = o < a.Cout, c_ok = c < Cin;
+    // lanes past the last input / output channel load from channel 0 of the first source (a valid address; x1 may be
+    // null) and are zeroed afterwards
+    const bool first = c < a.C0 || !c_ok;
+    const float* xsrc = first ? a.x0 : a.x1;
+    const int Cs = first ? a.C0 : a.C1, cs = !c_ok ? 0 : (first ? c : c - a.C0);
+    f32x4 acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    const int segs_x = (a.W + 63) / 64, units = a.n * a.H * segs_x;
+    for (int u = blockIdx.x * 4 + wave; u < units; u += gridDim.x * 4) {
+        const int n = u / (a.H * segs_x), r = u - n * a.H * segs_x, y = r / segs_x, xs = (r - y * segs_x) * 64;
+        const float* dyrow = a.dy + (((size_t)n * a.Cout + (o_ok ? o : 0)) * a.H + y) * a.W;
+        const float* xplane = xsrc + ((size_t)n * Cs + cs) * a.Hs * a.Ws;
+        const int xe = min(xs + 64, a.W);
+        for (int x0 = xs; x0 < xe; x0 += 16) {
+            const int px = x0 + q * 4;
+            float4 g = *reinterpret_cast<const float4*>(dyrow + px);
+            if (!o_ok) g = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+            if (a.db) bsum += (g.x + g.y) + (g.z + g.w);
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int yy = y + ky - P;
+                if (yy < 0 || yy >= a.H) continue;                  // wave-uniform
+                float v[4 + 2 * P];                                  // pixels px-P .. px+3+P of input row yy
+                if (a.up) {
+                    const float* row = xplane + (size_t)(yy >> 1) * a.Ws;
+                    const int s = px >> 1;
+                    const float2 t2 = *reinterpret_cast<const float2*>(row + s);
+                    v[P] = t2.x; v[P + 1] = t2.x; v[P + 2] = t2.y; v[P + 3] = t2.y;
+                    if (K == 3) {
+                        v[0] = row[max(s - 1, 0)];
+                        v[5] = row[min(s + 2, a.Ws - 1)];
+                    }
+                } else {
+                    const float* row = xplane + (size_t)yy * a.Ws;
+                    const float4 t4 = *reinterpret_cast<const float4*>(row + px);
+                    v[P] = t4.x; v[P + 1] = t4.y; v[P + 2] = t4.z; v[P + 3] = t4.w;
+                    if (K == 3) {
+                        v[0] = row[max(px - 1, 0)];
+                        v[5] = row[min(px + 4, a.W - 1)];
+                    }
+                }
+                if (K == 3) {
+                    if (px == 0) v[0] = 0.0f;                       // zero padding left / right of the image
+                    if (px + 4 >= a.W) v[5] = 0.0f;
+                }
+                if (!c_ok) {
+#pragma unroll
+                    for (int j = 0; j < 4 + 2 * P; ++j) v[j] = 0.0f;
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[ky * K + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[j], v[j + kx], acc[ky * K + kx], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: lane holds rows (output channels) 4*(lane>>4)+r, column (input channel) lane&15
+#pragma unroll
+    for (int t = 0; t < KK; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(t * 4 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    for (int e = tid; e < KK * 256; e += 256) {
+        const float sum = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const int l = e & 63, tr = e >> 6, t = tr >> 2, r = tr & 3;
+        const int oo = o0 + 4 * (l >> 4) + r, cc = c0 + (l & 15);
+        if (oo < a.Cout && cc < Cin) atomicAdd(&a.dw[((size_t)oo * Cin + cc) * KK + t], sum);
+    }
+    if (a.db && c0 == 0) {                                          // bias gradient: sum of dy over the pixels
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        if (q == 0 && o_ok) atomicAdd(&a.db[o], bsum);
+    }
+}
+
 // ---- BatchNorm (training) + LeakyReLU + Dropout -------------------------------------------------
 // per-channel double-precision sums over (n, HW): sums[c] += sum f1, sums[C + c] += sum f2
 template <int MODE>   // 0: f1 = v, f2 = v*v;  1: f1 = dz, f2 = dz * xhat
@@ -359,6 +456,17 @@ int gsa_train_conv_wgrad(void* stream, int32_t n, const float* x0, int32_t C0, c
     WgradArgs a{x0, x1, C0, C1, Hs, Ws, up, Hs << up, Ws << up, dy, Cout, dw, db, n};
     const int Cin = C0 + C1;
     const int pairs = ((Cout + 15) / 16) * ((Cin + 15) / 16), work = ((a.H + 15) / 16) * ((a.W + 15) / 16) * n;
+    const uintptr_t align = reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(dy);
+    if (a.W % 16 == 0 && a.W >= 16 && (align & 15) == 0) {   // matrix-core path (16-byte loads along the rows)
+        const int units = n * a.H * ((a.W + 63) / 64);
+        int gx = (1024 + pairs - 1) / pairs;      // ~1024 blocks (4096 waves) in all
+        gx = gx < 1 ? 1 : (gx > (units + 3) / 4 ? (units + 3) / 4 : gx);
+        const dim3 grid(gx, pairs, 1);
+        if (K == 3) hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        TRY_HIP(hipGetLastError());
+        return GSA_OK_;
+    }
     int gx = (1024 + pairs - 1) / pairs;          // ~1024 blocks in all: enough to fill the chip, few atomics per address
     gx = gx < 1 ? 1 : (gx > work ? work : gx);
     const dim3 grid(gx, pairs, 1);

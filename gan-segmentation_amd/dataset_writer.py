@@ -115,10 +115,15 @@ class DatasetWriter:
             self._encoders[slot] = enc
         if not img.is_contiguous():
             img = img.contiguous()
-        scan, lengths = enc.encode(img)
         cur = torch.cuda.current_stream(img.device)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=img.device)
+        # the encode runs on the copy stream, beside the next batch's generate kernels: its entropy-coding kernel is
+        # latency-bound (one lane per restart interval, a few hundred waves) and hides behind them
+        self._copy_stream.wait_stream(cur)
+        with torch.cuda.stream(self._copy_stream):
+            scan, lengths = enc.encode(img)
+        img.record_stream(self._copy_stream)
         buf = self._host[slot]
         if buf is None or buf.shape[0] < n or buf.shape[1:] != mask.shape[1:]:
             buf = torch.empty(tuple(mask.shape), dtype=torch.uint8).pin_memory()
