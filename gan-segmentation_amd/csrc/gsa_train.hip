@@ -93,6 +93,93 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     }
 }
 
+// The same convolution on the matrix cores (v_mfma_f32_16x16x4_f32) straight from NCHW: M = 16 consecutive pixels of
+// an output row, N = 16 output channels, K = input channels (4 per MFMA) x taps.  A lane (m = lane & 15, q = lane >> 4)
+// feeds pixel x0+m of channel 4i+q (one coalesced dword load per tap; concat / nearest-x2 resolved in the address) and
+// the weight of output channel o0+m from an LDS panel [tap][channel][16]; D comes out as 4 consecutive pixels of one
+// output channel per lane -> one 16-byte store.  A block (4 waves = 64 pixels of a row) walks many row segments with the
+// panel staged once (Cin <= 64) or per 64-channel slice.  W must be a multiple of 16.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int K>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    constexpr int P = K / 2, KK = K * K, CB = 64;
+    __shared__ float wl[KK][CB][16];
+    const int Cin = a.C0 + a.C1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m = lane & 15, q = lane >> 4;
+    const int o0 = blockIdx.y * 16;
+    const int chunks_x = a.W / 16, groups_x = (chunks_x + 3) / 4, units = gridDim.z * a.H * groups_x;
+    const bool single = Cin <= CB;
+    auto stage = [&](int cblk) {
+        const int cend = min(CB, Cin - cblk);
+        for (int i = tid; i < KK * cend * 16; i += 256) {
+            const int o = i & 15, cl = (i >> 4) % cend, t = i / (16 * cend);
+            const int oo = o0 + o, cc = cblk + cl;
+            float v = 0.0f;
+            if (oo < a.Cout)
+                v = a.transposed ? a.w[((size_t)cc * a.Cout + oo) * KK + (KK - 1 - t)] : a.w[((size_t)oo * Cin + cc) * KK + t];
+            wl[t][cl][o] = v;
+        }
+        for (int i = tid; i < KK * 3 * 16; i += 256) {     // zero the (up to 3) channels past cend that a 4-group may touch
+            const int o = i & 15, cl = cend + (i >> 4) % 3, t = i / 48;
+            if (cl < CB) wl[t][cl][o] = 0.0f;
+        }
+    };
+    if (single) { stage(0); __syncthreads(); }
+    for (int u = blockIdx.x + gridDim.x * blockIdx.z; u < units; u += gridDim.x * gridDim.z) {   // gridDim.z = batch size
+        const int n = u / (a.H * groups_x), r = u - n * a.H * groups_x, y = r / groups_x, grp = r - y * groups_x;
+        const int chunk = grp * 4 + wave;
+        const bool active = chunk < chunks_x;
+        const int x0 = (active ? chunk : 0) * 16;
+        int xoff[K], yoff[K];
+        bool xok[K], yok[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int xx = x0 + m + k - P, yy = y + k - P;
+            xok[k] = xx >= 0 && xx < a.W;
+            yok[k] = yy >= 0 && yy < a.H;
+            xoff[k] = min(max(xx, 0), a.W - 1) >> a.up;
+            yoff[k] = (min(max(yy, 0), a.H - 1) >> a.up) * a.Ws;
+        }
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cblk = 0; cblk < Cin; cblk += CB) {
+            if (!single) { __syncthreads(); stage(cblk); __syncthreads(); }
+            const int cend = min(CB, Cin - cblk);
+            for (int cl = 0; cl < cend; cl += 4) {
+                const int c = cblk + cl + q;
+                const bool cok = c < Cin;
+                const bool first = c < a.C0 || !cok;          // lanes past the last channel read channel 0 (valid address)
+                const float* src = first ? a.x0 : a.x1;
+                const int Cs = first ? a.C0 : a.C1, cs = !cok ? 0 : (first ? c : c - a.C0);
+                const float* plane = src + ((size_t)n * Cs + cs) * a.Hs * a.Ws;
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    if (!yok[ky]) continue;                     // uniform over the block
+                    const float* row = plane + yoff[ky];
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        float v = row[xoff[kx]];
+                        v = (xok[kx] && cok) ? v : 0.0f;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wl[ky * K + kx][cl + q][m], acc, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const int oo = o0 + m;                                  // D: column = output channel lane&15, rows = pixels 4q..4q+3
+        if (active && oo < a.Cout) {
+            const float b = a.bias ? a.bias[oo] : 0.0f;
+            float* dst = oo < a.Cout0 ? a.out0 + (((size_t)n * a.Cout0 + oo) * a.H + y) * a.W + x0 + 4 * q
+                                      : a.out1 + (((size_t)n * (a.Cout - a.Cout0) + (oo - a.Cout0)) * a.H + y) * a.W + x0 + 4 * q;
+            float4 v = make_float4(acc[0] + b, acc[1] + b, acc[2] + b, acc[3] + b);
+            if (a.accumulate) {
+                const float4 old = *reinterpret_cast<const float4*>(dst);
+                v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+            }
+            *reinterpret_cast<float4*>(dst) = v;
+        }
+    }
+}
+
 // ---- weight / bias gradient ---------------------------------------------------------------------
 struct WgradArgs {
     const float* x0; const float* x1; int C0, C1, Hs, Ws, up, H, W;
@@ -171,7 +258,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // both, so the four MFMAs of a 16-pixel chunk cover pixels {4q+j} -- a permutation of K, which a sum does not see.
 // A wave keeps the K*K 16x16 accumulators in registers over its share of 64-pixel row segments; the four waves of a
 // block are added in LDS and each block issues one float atomic per weight.  W must be a multiple of 16.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int K>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
@@ -441,6 +527,17 @@ int gsa_train_conv(void* stream, int32_t n, const float* x0, int32_t C0, const f
         (K != 1 && K != 3) || !out0 || Cout0 <= 0 || Cout0 > Cout || (Cout0 < Cout && !out1))
         return GSA_ERR_INVALID_;
     ConvArgs a{x0, x1, C0, C1, Hs, Ws, up, Hs << up, Ws << up, w, Cout, transposed, bias, out0, Cout0, out1, accumulate};
+    const uintptr_t align = reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(out1);
+    if (a.W % 16 == 0 && a.W >= 16 && (align & 15) == 0) {   // matrix-core path (16-byte stores along the rows)
+        const int units = n * a.H * ((a.W / 16 + 3) / 4), otiles = (Cout + 15) / 16;
+        int gx = (2048 + otiles * n - 1) / (otiles * n);   // ~2048 blocks in all; z carries the batch size
+        gx = gx > units / n ? units / n : gx;
+        const dim3 mgrid(gx, otiles, n);
+        if (K == 3) hipLaunchKernelGGL(conv_mfma_kernel<3>, mgrid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(conv_mfma_kernel<1>, mgrid, dim3(256), 0, (hipStream_t)stream, a);
+        TRY_HIP(hipGetLastError());
+        return GSA_OK_;
+    }
     const dim3 grid(((a.H + 15) / 16) * ((a.W + 15) / 16), (Cout + 15) / 16, n);
     if (K == 3) hipLaunchKernelGGL(conv_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
