@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 // feeds pixel x0+m of channel 4i+q (one coalesced dword load per tap; concat / nearest-x2 resolved in the address) and
 // the weight of output channel o0+m from an LDS panel [tap][channel][16]; D comes out as 4 consecutive pixels of one
 // output channel per lane -> one 16-byte store.  A block (4 waves = 64 pixels of a row) walks many row segments with the
-// panel staged once (Cin <= 64) or per 64-channel slice.  W must be a multiple of 16.
+// panel staged once (Cin <= 64) or per 64-channel slice.  W % 4 == 0 and H*W % 16 == 0 (chunks may span rows).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int K>
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int Cin = a.C0 + a.C1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m = lane & 15, q = lane >> 4;
     const int o0 = blockIdx.y * 16;
-    const int chunks_x = a.W / 16, groups_x = (chunks_x + 3) / 4, units = gridDim.z * a.H * groups_x;
+    const int HW = a.H * a.W, chunks = HW / 16, groups = (chunks + 3) / 4, units = gridDim.z * groups;
     const bool single = Cin <= CB;
     auto stage = [&](int cblk) {
         const int cend = min(CB, Cin - cblk);
@@ -126,25 +126,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         }
     };
     if (single) { stage(0); __syncthreads(); }
+    // a unit = 64 consecutive pixels of a sample's H*W plane (rows are contiguous, so 16-pixel chunks may span rows when
+    // W < 16): wave w takes chunk 4*group + w
     for (int u = blockIdx.x + gridDim.x * blockIdx.z; u < units; u += gridDim.x * gridDim.z) {   // gridDim.z = batch size
-        const int n = u / (a.H * groups_x), r = u - n * a.H * groups_x, y = r / groups_x, grp = r - y * groups_x;
+        const int n = u / groups, grp = u - n * groups;
         const int chunk = grp * 4 + wave;
-        const bool active = chunk < chunks_x;
-        const int x0 = (active ? chunk : 0) * 16;
-        int xoff[K], yoff[K];
-        bool xok[K], yok[K];
+        const bool active = chunk < chunks;
+        const int L0 = (active ? chunk : 0) * 16;
+        const int L = L0 + m, y = L / a.W, x = L - y * a.W;        // this lane's pixel as the A operand
+        int off[KK];
+        bool ok[KK];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int xx = x0 + m + k - P, yy = y + k - P;
-            xok[k] = xx >= 0 && xx < a.W;
-            yok[k] = yy >= 0 && yy < a.H;
-            xoff[k] = min(max(xx, 0), a.W - 1) >> a.up;
-            yoff[k] = (min(max(yy, 0), a.H - 1) >> a.up) * a.Ws;
-        }
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int xx = x + kx - P, yy = y + ky - P;
+                ok[ky * K + kx] = xx >= 0 && xx < a.W && yy >= 0 && yy < a.H;
+                off[ky * K + kx] = (min(max(yy, 0), a.H - 1) >> a.up) * a.Ws + (min(max(xx, 0), a.W - 1) >> a.up);
+            }
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int cblk = 0; cblk < Cin; cblk += CB) {
             if (!single) { __syncthreads(); stage(cblk); __syncthreads(); }
             const int cend = min(CB, Cin - cblk);
+#pragma unroll 2
             for (int cl = 0; cl < cend; cl += 4) {
                 const int c = cblk + cl + q;
                 const bool cok = c < Cin;
@@ -152,24 +156,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 const float* src = first ? a.x0 : a.x1;
                 const int Cs = first ? a.C0 : a.C1, cs = !cok ? 0 : (first ? c : c - a.C0);
                 const float* plane = src + ((size_t)n * Cs + cs) * a.Hs * a.Ws;
+                float v[KK];
 #pragma unroll
-                for (int ky = 0; ky < K; ++ky) {
-                    if (!yok[ky]) continue;                     // uniform over the block
-                    const float* row = plane + yoff[ky];
+                for (int t = 0; t < KK; ++t) v[t] = plane[off[t]];          // all loads of the group in flight together
 #pragma unroll
-                    for (int kx = 0; kx < K; ++kx) {
-                        float v = row[xoff[kx]];
-                        v = (xok[kx] && cok) ? v : 0.0f;
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wl[ky * K + kx][cl + q][m], acc, 0, 0, 0);
-                    }
-                }
+                for (int t = 0; t < KK; ++t)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32((ok[t] && cok) ? v[t] : 0.0f, wl[t][cl + q][m], acc, 0, 0, 0);
             }
         }
         const int oo = o0 + m;                                  // D: column = output channel lane&15, rows = pixels 4q..4q+3
         if (active && oo < a.Cout) {
             const float b = a.bias ? a.bias[oo] : 0.0f;
-            float* dst = oo < a.Cout0 ? a.out0 + (((size_t)n * a.Cout0 + oo) * a.H + y) * a.W + x0 + 4 * q
-                                      : a.out1 + (((size_t)n * (a.Cout - a.Cout0) + (oo - a.Cout0)) * a.H + y) * a.W + x0 + 4 * q;
+            float* dst = (oo < a.Cout0 ? a.out0 + ((size_t)n * a.Cout0 + oo) * HW
+                                       : a.out1 + ((size_t)n * (a.Cout - a.Cout0) + (oo - a.Cout0)) * HW) + L0 + 4 * q;
             float4 v = make_float4(acc[0] + b, acc[1] + b, acc[2] + b, acc[3] + b);
             if (a.accumulate) {
                 const float4 old = *reinterpret_cast<const float4*>(dst);
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // aligned 16-byte load per input row plus the two neighbours for the horizontal taps); MFMA j multiplies element j of
 // both, so the four MFMAs of a 16-pixel chunk cover pixels {4q+j} -- a permutation of K, which a sum does not see.
 // A wave keeps the K*K 16x16 accumulators in registers over its share of 64-pixel row segments; the four waves of a
-// block are added in LDS and each block issues one float atomic per weight.  W must be a multiple of 16.
+// block are added in LDS and each block issues one float atomic per weight.  W % 4 == 0 and H*W % 16 == 0.
 
 template <int K>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
@@ -277,55 +276,59 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
-    const int segs_x = (a.W + 63) / 64, units = a.n * a.H * segs_x;
+    const int HW = a.H * a.W, segs = (HW + 63) / 64, units = a.n * segs;
+    // a unit = 64 consecutive pixels of a sample's H*W plane; a lane's 4 pixels lie in one row (W % 4 == 0)
     for (int u = blockIdx.x * 4 + wave; u < units; u += gridDim.x * 4) {
-        const int n = u / (a.H * segs_x), r = u - n * a.H * segs_x, y = r / segs_x, xs = (r - y * segs_x) * 64;
-        const float* dyrow = a.dy + (((size_t)n * a.Cout + (o_ok ? o : 0)) * a.H + y) * a.W;
+        const int n = u / segs, L0 = (u - n * segs) * 64;
+        const float* dyplane = a.dy + ((size_t)n * a.Cout + (o_ok ? o : 0)) * HW;
         const float* xplane = xsrc + ((size_t)n * Cs + cs) * a.Hs * a.Ws;
-        const int xe = min(xs + 64, a.W);
-        for (int x0 = xs; x0 < xe; x0 += 16) {
-            const int px = x0 + q * 4;
-            float4 g = *reinterpret_cast<const float4*>(dyrow + px);
+        const int Le = min(L0 + 64, HW);
+        for (int Lc = L0; Lc < Le; Lc += 16) {
+            const int Lp = Lc + q * 4, y = Lp / a.W, x = Lp - y * a.W;
+            float4 g = *reinterpret_cast<const float4*>(dyplane + Lp);
             if (!o_ok) g = make_float4(0.f, 0.f, 0.f, 0.f);
             const float gv[4] = {g.x, g.y, g.z, g.w};
             if (a.db) bsum += (g.x + g.y) + (g.z + g.w);
+            float v[K][4 + 2 * P];                                   // pixels x-P .. x+3+P of the K input rows
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
                 const int yy = y + ky - P;
-                if (yy < 0 || yy >= a.H) continue;                  // wave-uniform
-                float v[4 + 2 * P];                                  // pixels px-P .. px+3+P of input row yy
+                const bool yok = yy >= 0 && yy < a.H && c_ok;
+                const int yc = min(max(yy, 0), a.H - 1);
                 if (a.up) {
-                    const float* row = xplane + (size_t)(yy >> 1) * a.Ws;
-                    const int s = px >> 1;
-                    const float2 t2 = *reinterpret_cast<const float2*>(row + s);
-                    v[P] = t2.x; v[P + 1] = t2.x; v[P + 2] = t2.y; v[P + 3] = t2.y;
+                    const float* row = xplane + (size_t)(yc >> 1) * a.Ws;
+                    const int s2 = x >> 1;
+                    const float2 t2 = *reinterpret_cast<const float2*>(row + s2);
+                    v[ky][P] = t2.x; v[ky][P + 1] = t2.x; v[ky][P + 2] = t2.y; v[ky][P + 3] = t2.y;
                     if (K == 3) {
-                        v[0] = row[max(s - 1, 0)];
-                        v[5] = row[min(s + 2, a.Ws - 1)];
+                        v[ky][0] = row[max(s2 - 1, 0)];
+                        v[ky][5] = row[min(s2 + 2, a.Ws - 1)];
                     }
                 } else {
-                    const float* row = xplane + (size_t)yy * a.Ws;
-                    const float4 t4 = *reinterpret_cast<const float4*>(row + px);
-                    v[P] = t4.x; v[P + 1] = t4.y; v[P + 2] = t4.z; v[P + 3] = t4.w;
+                    const float* row = xplane + (size_t)yc * a.Ws;
+                    const float4 t4 = *reinterpret_cast<const float4*>(row + x);
+                    v[ky][P] = t4.x; v[ky][P + 1] = t4.y; v[ky][P + 2] = t4.z; v[ky][P + 3] = t4.w;
                     if (K == 3) {
-                        v[0] = row[max(px - 1, 0)];
-                        v[5] = row[min(px + 4, a.W - 1)];
+                        v[ky][0] = row[max(x - 1, 0)];
+                        v[ky][5] = row[min(x + 4, a.W - 1)];
                     }
                 }
                 if (K == 3) {
-                    if (px == 0) v[0] = 0.0f;                       // zero padding left / right of the image
-                    if (px + 4 >= a.W) v[5] = 0.0f;
+                    if (x == 0) v[ky][0] = 0.0f;                    // zero padding left / right of the image
+                    if (x + 4 >= a.W) v[ky][5] = 0.0f;
                 }
-                if (!c_ok) {
+                if (!yok) {
 #pragma unroll
-                    for (int j = 0; j < 4 + 2 * P; ++j) v[j] = 0.0f;
+                    for (int j = 0; j < 4 + 2 * P; ++j) v[ky][j] = 0.0f;
                 }
+            }
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[ky * K + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[j], v[j + kx], acc[ky * K + kx], 0, 0, 0);
-            }
+                        acc[ky * K + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[j], v[ky][j + kx], acc[ky * K + kx], 0, 0, 0);
         }
     }
     // D layout: lane holds rows (output channels) 4*(lane>>4)+r, column (input channel) lane&15
@@ -528,10 +531,10 @@ int gsa_train_conv(void* stream, int32_t n, const float* x0, int32_t C0, const f
         return GSA_ERR_INVALID_;
     ConvArgs a{x0, x1, C0, C1, Hs, Ws, up, Hs << up, Ws << up, w, Cout, transposed, bias, out0, Cout0, out1, accumulate};
     const uintptr_t align = reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(out1);
-    if (a.W % 16 == 0 && a.W >= 16 && (align & 15) == 0) {   // matrix-core path (16-byte stores along the rows)
-        const int units = n * a.H * ((a.W / 16 + 3) / 4), otiles = (Cout + 15) / 16;
+    if (a.W % 4 == 0 && (a.H * a.W) % 16 == 0 && (align & 15) == 0) {   // matrix-core path (16-byte stores along the rows)
+        const int groups = (a.H * a.W / 16 + 3) / 4, otiles = (Cout + 15) / 16;
         int gx = (2048 + otiles * n - 1) / (otiles * n);   // ~2048 blocks in all; z carries the batch size
-        gx = gx > units / n ? units / n : gx;
+        gx = gx > groups ? groups : gx;
         const dim3 mgrid(gx, otiles, n);
         if (K == 3) hipLaunchKernelGGL(conv_mfma_kernel<3>, mgrid, dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(conv_mfma_kernel<1>, mgrid, dim3(256), 0, (hipStream_t)stream, a);
@@ -554,8 +557,8 @@ int gsa_train_conv_wgrad(void* stream, int32_t n, const float* x0, int32_t C0, c
     const int Cin = C0 + C1;
     const int pairs = ((Cout + 15) / 16) * ((Cin + 15) / 16), work = ((a.H + 15) / 16) * ((a.W + 15) / 16) * n;
     const uintptr_t align = reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(dy);
-    if (a.W % 16 == 0 && a.W >= 16 && (align & 15) == 0) {   // matrix-core path (16-byte loads along the rows)
-        const int units = n * a.H * ((a.W + 63) / 64);
+    if (a.W % 4 == 0 && (a.H * a.W) % 16 == 0 && (align & 15) == 0) {   // matrix-core path (16-byte loads along the rows)
+        const int units = n * ((a.H * a.W + 63) / 64);
         int gx = (1024 + pairs - 1) / pairs;      // ~1024 blocks (4096 waves) in all
         gx = gx < 1 ? 1 : (gx > (units + 3) / 4 ? (units + 3) / 4 : gx);
         const dim3 grid(gx, pairs, 1);
