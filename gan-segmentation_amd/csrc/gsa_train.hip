@@ -1,13 +1,14 @@
 // Decoder-training operators for gfx950 behind the C ABI include/gsa_train.h.
 //
 // Training the reference's decoder is a few annotated images at batch size 1 for 24 epochs
-// (seg_solver.py:83-132): throughput is irrelevant next to the generate path, so these kernels are plain
-// LDS-tiled vector-ALU code in the reference's own NCHW / OIHW layouts -- one kernel serves the forward
-// convolution and, with the weight read transposed and flipped, its input gradient; a second one the weight
-// gradient.  Nothing here is shared with the inference kernels, and nothing here is order-canonical.
+// (seg_solver.py:83-132).  The kernels work in the reference's own NCHW / OIHW layouts: one convolution kernel
+// serves the forward pass and, with the weight read transposed and flipped, the input gradient; a second one
+// the weight gradient.  Both run on the matrix cores (v_mfma_f32_16x16x4_f32) straight from global memory when
+// W % 4 == 0 and H*W % 16 == 0 (every decoder layer); the LDS-tiled vector-ALU forms remain for other shapes.
+// Nothing here is shared with the inference kernels, and nothing here is order-canonical.
 //
-//   conv_kernel<K>      nn.Conv2D 3x3 / 1x1 (+ concat, + nearest x2 on read) and its dgrad   networks_seg.py:14-41,68,91
-//   wgrad_kernel<K>     dL/dW, dL/db of the same convolution                                  (autograd)
+//   conv_mfma_kernel<K> / conv_kernel<K>     nn.Conv2D 3x3 / 1x1 (+ concat, + nearest x2 on read) and its dgrad   networks_seg.py:14-41,68,91
+//   wgrad_mfma_kernel<K> / wgrad_kernel<K>   dL/dW, dL/db of the same convolution                                  (autograd)
 //   bn_*                nn.BatchNorm (training mode) + LeakyReLU(0.2) + Dropout mask          networks_seg.py:17-32,69-78
 //   softmax_ce_kernel   SoftmaxCELoss(axis=1) with sample weights                             seg_solver.py:395-407
 //   adam_kernel         mx.optimizer.Adam                                                     seg_solver.py:203-219
