@@ -15,7 +15,7 @@ _FUNCS = None
 
 DEFAULT_QUALITY = 95     # cv2.imwrite's default JPEG quality (the reference passes none)
 DEFAULT_RESTART = 2      # MCUs (16x16 px) per restart interval: 2048 independent lanes per 1024^2 image; measured on
-#                          8 FFHQ-size images: restart 1 -> 0.18 ms (+1.5 % bytes), 2 -> 0.26 ms (+0.5 %), 4 -> 0.46 ms, 8 -> 0.88 ms
+#                          8 FFHQ-size images: restart 1 -> 0.14 ms (+1.5 % bytes), 2 -> 0.21 ms (+0.5 %), 4 -> 0.36 ms
 
 
 def _api():

@@ -21,7 +21,8 @@ def _close(a, b, tol=2e-4):
 
 @pytest.mark.parametrize("C0,C1,Cout,K,up,R", [(16, 0, 16, 3, 0, 20), (8, 8, 12, 3, 1, 8), (32, 32, 2, 3, 0, 16), (24, 8, 16, 1, 1, 8),
                                                (512, 0, 32, 3, 0, 4), (16, 16, 16, 3, 1, 40), (16, 0, 32, 3, 0, 80),
-                                               (40, 0, 24, 1, 0, 48)])
+                                               (40, 0, 24, 1, 0, 48),
+                                               (8, 4, 6, 3, 0, 6), (6, 0, 4, 1, 1, 5)])     # W % 4 != 0: the vector-ALU fallbacks
 def test_conv_forward_dgrad_wgrad(T, C0, C1, Cout, K, up, R):
     import torch.nn.functional as F
     from gan_segmentation_amd import train_ops as ops

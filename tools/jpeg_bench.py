@@ -8,14 +8,14 @@ import numpy as np
 import torch
 
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
-from gan_segmentation_amd.jpeg import JpegEncoder  # noqa: E402
+from gan_segmentation_amd.jpeg import DEFAULT_RESTART, JpegEncoder  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--restart", type=int, default=4)
+    ap.add_argument("--restart", type=int, default=DEFAULT_RESTART)
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     g = torch.Generator(device="cuda").manual_seed(0)
