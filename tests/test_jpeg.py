@@ -148,3 +148,20 @@ def test_dataset_writer_with_gpu_jpeg(torch_cuda, tmp_path):
         ref = np.asarray(Image.open(io.BytesIO(pillow_bytes(img[i], 95, 0))).convert("RGB"))
         assert np.array_equal(got, ref), i
         assert np.array_equal(np.asarray(Image.open(tmp_path / ("mask_%06d.png" % i))), mask[i])
+
+
+def test_encode_rejects_bad_arguments_before_touching_the_gpu(hip_library):
+    """Argument validation of gsa_jpeg_encode happens on the host (no HIP call precedes it): sizes that are not
+    multiples of 16, a missing restart interval, null / misaligned pointers, a workspace that is too small."""
+    from gan_segmentation_amd import jpeg
+    enc = jpeg._api()["gsa_jpeg_encode"]
+    ws = jpeg._api()["gsa_jpeg_workspace_bytes"](1, 64, 64, 2)
+    good = dict(n=1, H=64, W=64, rgb=4096, q=95, ri=2, ws=8192, wsb=ws, out=16384, stride=1 << 20, ln=32768)
+
+    def call(**kw):
+        a = dict(good, **kw)
+        return enc(None, a["n"], a["H"], a["W"], a["rgb"], a["q"], a["ri"], a["ws"], a["wsb"], a["out"], a["stride"], a["ln"])
+
+    for bad in (dict(n=0), dict(H=60), dict(W=8), dict(ri=0), dict(ri=70000), dict(rgb=None), dict(rgb=4097), dict(ws=None),
+                dict(wsb=ws - 1), dict(out=None), dict(ln=None), dict(stride=1), dict(H=65536 + 16)):
+        assert call(**bad) == -1, bad
