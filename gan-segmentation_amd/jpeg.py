@@ -55,7 +55,8 @@ class JpegEncoder:
         ws = api["gsa_jpeg_workspace_bytes"](n, H, W, restart)
         worst = api["gsa_jpeg_max_scan_bytes"](H, W, restart)
         if ws < 0 or worst < 0:
-            raise ValueError("JPEG encoder: images must be multiples of 16 px (got %dx%d), restart in 1..65535" % (H, W))
+            raise ValueError("JPEG encoder: images must be multiples of 16 px (got %dx%d), restart in 1..65535; other "
+                             "sizes go through the host encoder (DatasetWriter(gpu_jpeg=False) / JPEG_ON_GPU: false)" % (H, W))
         self.header = header(H, W, quality, restart)
         # default stride: the size of the raw pixels (a q95 scan is ~1/7 of it; noise at q100 can exceed it -> the
         # call reports the size needed as a negative length and encode() retries with the worst-case stride)
