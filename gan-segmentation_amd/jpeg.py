@@ -76,9 +76,10 @@ class JpegEncoder:
         k = img.shape[0]
         if k > self.n or tuple(img.shape[1:]) != (self.H, self.W, 3):
             raise ValueError("image batch %s does not fit the encoder (%d, %d, %d, 3)" % (tuple(img.shape), self.n, self.H, self.W))
-        rc = _api()["gsa_jpeg_encode"](current_stream_ptr(img.device), k, self.H, self.W, img.data_ptr(), self.quality,
-                                       self.restart, self._ws.data_ptr(), self._ws.numel(), self.out.data_ptr(),
-                                       self.out_stride, self.lengths.data_ptr())
+        with torch.cuda.device(img.device):     # the C ABI is stateless: kernels go to the calling thread's current device
+            rc = _api()["gsa_jpeg_encode"](current_stream_ptr(img.device), k, self.H, self.W, img.data_ptr(), self.quality,
+                                           self.restart, self._ws.data_ptr(), self._ws.numel(), self.out.data_ptr(),
+                                           self.out_stride, self.lengths.data_ptr())
         if rc != 0:
             raise _lib.GsaError("gsa_jpeg_encode failed (%d)" % rc)
         return self.out[:k], self.lengths[:k]
