@@ -69,6 +69,10 @@ class DecoderTrainer:
     def step(self, features, labels, masks=None):
         """features: list of (n,C_i,R_i,R_i) fp32 arrays/tensors; labels (n,H,W) integers, -1 = ignore.
         ``masks``: explicit dropout keep masks (tests); default: counter-based.  -> mean loss of the batch."""
+        with torch.cuda.device(self.dev):    # the training C ABI is stateless: launches go to the current device
+            return self._step(features, labels, masks)
+
+    def _step(self, features, labels, masks):
         p, g, F, nl, s0 = self.p, self.g, self.F, self.n_levels, self.s0
         feats = [torch.as_tensor(np.asarray(f) if not torch.is_tensor(f) else f, dtype=torch.float32).to(self.dev).contiguous()
                  for f in features]
