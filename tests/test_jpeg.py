@@ -53,6 +53,18 @@ def test_oracle_is_byte_identical_to_libjpeg_turbo(H, W, quality, restart):
         assert ours == ref, "%s %dx%d q%d ri%d: %d vs %d bytes" % (kind, H, W, quality, restart, len(ours), len(ref))
 
 
+def test_oracle_reproduces_the_committed_libjpeg_turbo_files():
+    """The same pin without Pillow: files libjpeg-turbo wrote (tests/golden/make_jpeg_golden.py) for three images at
+    three quality / restart settings."""
+    from oracle import jpeg_binding as J
+    g = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_libjpeg_turbo.npz"))
+    keys = [k[:-4] for k in g.files if k.endswith("_rgb")]
+    assert len(keys) == 9
+    for k in keys:
+        quality, restart = int(k.split("_q")[1].split("_")[0]), int(k.split("_ri")[1])
+        assert J.encode(g[k + "_rgb"], quality, restart) == g[k + "_jpg"].tobytes(), k
+
+
 def test_header_of_the_product_library(hip_library):
     """gsa_jpeg_header (host function of the HIP library) == the oracle's == the front of Pillow's file."""
     from oracle import jpeg_binding as J
