@@ -64,25 +64,36 @@ def write_pair(dst_dir, index, img, mask, jpeg_quality=95):
     _write_mask(dst_dir, index, mask)
 
 
-def write_encoded_pair(dst_dir, index, header, scan, mask):
-    """The image already encoded on the GPU (header + scan bytes), the mask as PNG."""
-    with open(os.path.join(dst_dir, "img_%06d.jpg" % index), "wb") as f:
-        f.write(header)
-        f.write(scan)
-    _write_mask(dst_dir, index, mask)
+def write_encoded_pair(dst_dir, index, jpeg_parts, img, png_stream, mask, H, W, jpeg_quality=95):
+    """One pair whose image and/or mask were already compressed on the GPU: ``jpeg_parts`` = (header, scan) or None
+    (then ``img`` is encoded here), ``png_stream`` = the zlib stream of the mask or None (then ``mask`` is encoded here)."""
+    if jpeg_parts is not None:
+        with open(os.path.join(dst_dir, "img_%06d.jpg" % index), "wb") as f:
+            f.write(jpeg_parts[0])
+            f.write(jpeg_parts[1])
+    else:
+        from PIL import Image
+        Image.fromarray(img, "RGB").save(os.path.join(dst_dir, "img_%06d.jpg" % index), quality=jpeg_quality)
+    if png_stream is not None:
+        from .png import png_file
+        with open(os.path.join(dst_dir, "mask_%06d.png" % index), "wb") as f:
+            f.write(png_file(H, W, png_stream))
+    else:
+        _write_mask(dst_dir, index, mask)
 
 
 class DatasetWriter:
     """``submit(img, mask, first_index)`` returns immediately; ``close()`` waits for every file."""
 
-    def __init__(self, dst_dir, workers=None, slots=3, jpeg_quality=95, gpu_jpeg=False, jpeg_restart=None):
+    def __init__(self, dst_dir, workers=None, slots=3, jpeg_quality=95, gpu_jpeg=False, jpeg_restart=None, gpu_png=False):
         self.dst_dir = dst_dir
         os.makedirs(dst_dir, exist_ok=True)
         self.jpeg_quality = jpeg_quality
         self.gpu_jpeg = gpu_jpeg
+        self.gpu_png = gpu_png
         self.jpeg_restart = jpeg_restart
-        self._encoders = [None] * slots      # one JpegEncoder (output buffers) per slot
-        self._stage = [None] * slots         # pinned staging for the compressed bytes
+        self._encoders = [{} for _ in range(slots)]   # per slot: {"jpeg": JpegEncoder, "png": PngEncoder} (own output buffers)
+        self._stage = [{} for _ in range(slots)]      # per slot and kind: pinned staging for the compressed bytes
         self.pool = ThreadPoolExecutor(max_workers=workers or default_workers())
         self.slots = slots
         self._free = queue.Queue()
@@ -108,7 +119,7 @@ class DatasetWriter:
         import torch
         slot = self._free.get()               # back-pressure: at most `slots` batches in flight
         n = img.shape[0]
-        if self.gpu_jpeg:
+        if self.gpu_jpeg or self.gpu_png:
             return self._submit_encoded(slot, img, mask, first_index)
         buf = self._host[slot]
         if buf is None or buf[0].shape[0] < n or buf[0].shape[1:] != img.shape[1:]:
@@ -128,56 +139,79 @@ class DatasetWriter:
         mask.record_stream(self._copy_stream)
         self._pending.put((slot, ev, buf[0][:n].numpy(), buf[1][:n].numpy(), first_index))
 
+    def _encoder(self, slot, kind, n, H, W, device):
+        enc = self._encoders[slot].get(kind)
+        if enc is None or enc.n < n or (enc.H, enc.W) != (H, W) or enc.device != device:
+            if kind == "jpeg":
+                from . import jpeg
+                kw = {} if self.jpeg_restart is None else {"restart": self.jpeg_restart}
+                worst = jpeg._api()["gsa_jpeg_max_scan_bytes"](H, W, kw.get("restart", jpeg.DEFAULT_RESTART))
+                enc = jpeg.JpegEncoder(n, H, W, device, quality=self.jpeg_quality, out_stride=worst, **kw)
+            else:
+                from . import png
+                enc = png.PngEncoder(n, H, W, device)
+            self._encoders[slot][kind] = enc
+        return enc
+
     def _submit_encoded(self, slot, img, mask, first_index):
-        """Encode on the producing stream (right behind the generate kernels); the dispatcher thread then fetches
-        the lengths and exactly the compressed bytes."""
+        """Compress on the GPU right behind the generate kernels; the dispatcher thread then fetches the lengths and
+        exactly the compressed bytes.  Whatever is not compressed on the GPU is copied out raw, as in the host path."""
         import torch
-        from . import jpeg
         n, H, W = img.shape[0], img.shape[1], img.shape[2]
-        enc = self._encoders[slot]
-        if enc is None or enc.n < n or (enc.H, enc.W) != (H, W) or enc.device != img.device:
-            kw = {} if self.jpeg_restart is None else {"restart": self.jpeg_restart}
-            worst = jpeg._api()["gsa_jpeg_max_scan_bytes"](H, W, kw.get("restart", jpeg.DEFAULT_RESTART))
-            enc = jpeg.JpegEncoder(n, H, W, img.device, quality=self.jpeg_quality, out_stride=worst, **kw)
-            self._encoders[slot] = enc
-        if not img.is_contiguous():
-            img = img.contiguous()
         cur = torch.cuda.current_stream(img.device)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=img.device)
-        # the encode runs on the copy stream, beside the next batch's generate kernels: its entropy-coding kernel is
-        # latency-bound (one lane per restart interval, a few hundred waves) and hides behind them
+        if not img.is_contiguous():
+            img = img.contiguous()
+        if not mask.is_contiguous():
+            mask = mask.contiguous()
+        def pinned(kind, like):                      # raw pinned buffer for whatever is not compressed on the GPU
+            raw = self._stage[slot].get(kind)
+            if raw is None or raw.shape[0] < n or raw.shape[1:] != like.shape[1:]:
+                raw = torch.empty(tuple(like.shape), dtype=torch.uint8).pin_memory()
+                self._stage[slot][kind] = raw
+            return raw[:n]
+
+        payload = {"n": n, "H": H, "W": W}
+        # the encoders run on the copy stream, beside the next batch's generate kernels: their entropy-coding kernels
+        # are latency-bound (one lane per restart interval / row group, a few hundred waves) and hide behind them
         self._copy_stream.wait_stream(cur)
         with torch.cuda.stream(self._copy_stream):
-            scan, lengths = enc.encode(img)
-        img.record_stream(self._copy_stream)
-        buf = self._host[slot]
-        if buf is None or buf.shape[0] < n or buf.shape[1:] != mask.shape[1:]:
-            buf = torch.empty(tuple(mask.shape), dtype=torch.uint8).pin_memory()
-            self._host[slot] = buf
-        self._copy_stream.wait_stream(cur)
-        with torch.cuda.stream(self._copy_stream):
-            buf[:n].copy_(mask, non_blocking=True)
+            if self.gpu_jpeg:
+                enc = self._encoder(slot, "jpeg", n, H, W, img.device)
+                payload["jpeg"] = (enc,) + tuple(enc.encode(img))
+            else:
+                raw = pinned("raw_img", img)
+                raw.copy_(img, non_blocking=True)
+                payload["img"] = raw.numpy()
+            if self.gpu_png:
+                enc = self._encoder(slot, "png", n, H, W, img.device)
+                payload["png"] = (enc,) + tuple(enc.encode(mask))
+            else:
+                raw = pinned("raw_mask", mask)
+                raw.copy_(mask, non_blocking=True)
+                payload["mask"] = raw.numpy()
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
+        img.record_stream(self._copy_stream)
         mask.record_stream(self._copy_stream)
-        self._pending.put((slot, ev, (enc, scan, lengths), buf[:n].numpy(), first_index))
+        self._pending.put((slot, ev, payload, None, first_index))
 
-    def _fetch_encoded(self, slot, enc, scan, lengths):
-        """-> list of numpy views (one per image) of the compressed bytes in pinned memory."""
+    def _fetch_encoded(self, slot, kind, out, lengths):
+        """-> list of numpy views (one per sample) of the compressed bytes in pinned memory."""
         import torch
-        n = scan.shape[0]
+        n = out.shape[0]
         with torch.cuda.stream(self._copy_stream):
-            ln = lengths.to("cpu", non_blocking=False).numpy().astype(np.int64)     # 4 bytes per image; synchronises
+            ln = lengths.to("cpu", non_blocking=False).numpy().astype(np.int64)     # 4 bytes per sample; synchronises
             if (ln <= 0).any():
-                raise RuntimeError("JPEG encoder overflow (lengths %s)" % ln)        # impossible with the worst-case stride
+                raise RuntimeError("%s encoder overflow (lengths %s)" % (kind, ln))  # impossible with the worst-case stride
             offs = np.concatenate([[0], np.cumsum(ln)])
-            stage = self._stage[slot]
+            stage = self._stage[slot].get(kind)
             if stage is None or stage.numel() < offs[-1]:
-                stage = torch.empty(int(max(offs[-1] * 3 // 2, 1 << 20)), dtype=torch.uint8).pin_memory()
-                self._stage[slot] = stage
+                stage = torch.empty(int(max(offs[-1] * 3 // 2, 1 << 16)), dtype=torch.uint8).pin_memory()
+                self._stage[slot][kind] = stage
             for i in range(n):
-                stage[offs[i]:offs[i + 1]].copy_(scan[i, :ln[i]], non_blocking=True)
+                stage[offs[i]:offs[i + 1]].copy_(out[i, :ln[i]], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
         ev.synchronize()
@@ -195,10 +229,16 @@ class DatasetWriter:
             try:
                 if ev is not None:
                     ev.synchronize()
-                if isinstance(img, tuple):        # encoded on the GPU: (encoder, scan, lengths)
-                    scans = self._fetch_encoded(slot, *img)
-                    futs = [self.pool.submit(write_encoded_pair, self.dst_dir, first + i, img[0].header, scans[i], mask[i])
-                            for i in range(len(scans))]
+                if isinstance(img, dict):         # (partly) compressed on the GPU
+                    p = img
+                    scans = self._fetch_encoded(slot, "jpeg", *p["jpeg"][1:]) if "jpeg" in p else None
+                    streams = self._fetch_encoded(slot, "png", *p["png"][1:]) if "png" in p else None
+                    futs = [self.pool.submit(write_encoded_pair, self.dst_dir, first + i,
+                                             (p["jpeg"][0].header, scans[i]) if scans is not None else None,
+                                             p["img"][i] if "img" in p else None,
+                                             streams[i] if streams is not None else None,
+                                             p["mask"][i] if "mask" in p else None, p["H"], p["W"], self.jpeg_quality)
+                            for i in range(p["n"])]
                 else:
                     futs = [self.pool.submit(write_pair, self.dst_dir, first + i, img[i], mask[i], self.jpeg_quality)
                             for i in range(img.shape[0])]

@@ -52,8 +52,10 @@ def generate(cfg, limit=None, workers=None):
     index = lo
     # the writer copies each batch out through pinned buffers and encodes it on a thread pool while the
     # GPU already computes the next one
-    # additive key JPEG_ON_GPU (default on): the image files are encoded by the HIP baseline-JPEG kernels
-    with DatasetWriter(dst_dir, workers=workers, gpu_jpeg=bool(cfg.get("JPEG_ON_GPU", True))) as writer:
+    # additive keys JPEG_ON_GPU / PNG_ON_GPU (default on): the files are compressed by the HIP kernels behind
+    # include/gsa_jpeg.h and include/gsa_png.h; the host threads only frame and write them
+    on_gpu = bool(cfg.get("JPEG_ON_GPU", True))
+    with DatasetWriter(dst_dir, workers=workers, gpu_jpeg=on_gpu, gpu_png=bool(cfg.get("PNG_ON_GPU", on_gpu))) as writer:
         while index < hi:
             bs = min(batch, hi - index)
             # latents and noise keyed on the global sample index: the files are the same for any number of ranks

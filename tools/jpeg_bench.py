@@ -33,9 +33,24 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / a.iters
     ln = lengths.cpu().numpy()
-    print("res %d batch %d restart %d: %.3f ms per batch, %.0f images/s, %.0f bytes/image (%.1f %% of the pixels)"
+    print("jpeg: res %d batch %d restart %d: %.3f ms per batch, %.0f images/s, %.0f bytes/image (%.1f %% of the pixels)"
           % (a.res, a.batch, a.restart, dt * 1e3, a.batch / dt, ln.mean() + len(enc.header),
              100.0 * ln.mean() / (a.res * a.res * 3)))
+    # the mask compressor on blob masks of the same size
+    from gan_segmentation_amd.png import PngEncoder
+    m = torch.nn.functional.interpolate(torch.randn((a.batch, 1, 8, 8), device="cuda", generator=g), size=(a.res, a.res), mode="bicubic")
+    mask = (m[:, 0] > 0).to(torch.uint8).contiguous()
+    penc = PngEncoder(a.batch, a.res, a.res, "cuda:0")
+    for _ in range(3):
+        _s, plen = penc.encode(mask)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(a.iters):
+        penc.encode(mask)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / a.iters
+    print("png:  res %d batch %d: %.3f ms per batch, %.0f masks/s, %.0f bytes/mask (%.2f %% of the pixels)"
+          % (a.res, a.batch, dt * 1e3, a.batch / dt, plen.cpu().numpy().mean() + 57, 100.0 * plen.cpu().numpy().mean() / (a.res * a.res)))
 
 
 if __name__ == "__main__":

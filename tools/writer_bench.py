@@ -26,17 +26,18 @@ img = img.permute(0, 2, 3, 1).contiguous()
 m = torch.nn.functional.interpolate(torch.randn((pool, 1, 8, 8), device="cuda", generator=g), size=(res, res), mode="bicubic")
 mask = (m[:, 0] > 0).to(torch.uint8).contiguous()
 
-for gpu_jpeg in (False, True):
+for gpu_jpeg, gpu_png in ((False, False), (True, False), (True, True)):
     with tempfile.TemporaryDirectory() as d:
-        with DatasetWriter(d, workers=workers, gpu_jpeg=gpu_jpeg) as w:       # warm-up: buffers, encoder, pool
+        with DatasetWriter(d, workers=workers, gpu_jpeg=gpu_jpeg, gpu_png=gpu_png) as w:   # warm-up: buffers, encoders, pool
             w.submit(img[:batch], mask[:batch], 0)
         torch.cuda.synchronize()
         t = time.perf_counter()
-        with DatasetWriter(d, workers=workers, gpu_jpeg=gpu_jpeg) as w:
+        with DatasetWriter(d, workers=workers, gpu_jpeg=gpu_jpeg, gpu_png=gpu_png) as w:
             for k in range(pairs // batch):
                 o = (k * batch) % pool
                 w.submit(img[o:o + batch], mask[o:o + batch], k * batch)
         dt = time.perf_counter() - t
         size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)) / (len(os.listdir(d)) / 2.0)
-        print("%d^2, batch %d, %s workers, jpeg on %s: %d pairs in %.2f s = %.0f pairs/s (%.0f KB per pair on disk)"
-              % (res, batch, workers or default_workers(), "GPU" if gpu_jpeg else "host", pairs, dt, pairs / dt, size / 1e3))
+        print("%d^2, batch %d, %s workers, jpeg on %s, png on %s: %d pairs in %.2f s = %.0f pairs/s (%.0f KB per pair on disk)"
+              % (res, batch, workers or default_workers(), "GPU" if gpu_jpeg else "host", "GPU" if gpu_png else "host", pairs, dt,
+                 pairs / dt, size / 1e3))
