@@ -174,35 +174,52 @@ __global__ __launch_bounds__(256) void png_offsets_kernel(const int* __restrict_
                                                           int* __restrict__ lengths, uint8_t* __restrict__ out,
                                                           long long out_stride) {
     __shared__ int wsum[4];
+    __shared__ unsigned long long wsum1[4], wterm[4];
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int carry = 2;                                      // the segments follow the 2-byte zlib header
+    // Adler-32 of the concatenation without a serial pass: with S1_s = sum of segment s's bytes, S2_s = its own weighted
+    // sum and L_s its length,  A = 1 + sum S1_s,  B = L_total + sum_s [ S2_s + L_s * (S1_0 + .. + S1_{s-1}) ]   (mod 65521)
+    unsigned long long carry1 = 0, bsum = 0;            // sum of S1 so far; running sum of the bracket
     for (int base = 0; base < segs_per_img; base += 256) {
         const int i = base + tid;
-        const int v = i < segs_per_img ? seglen[(size_t)img * segs_per_img + i] : 0;
+        const bool in = i < segs_per_img;
+        const size_t g = (size_t)img * segs_per_img + (in ? i : 0);
+        const int v = in ? seglen[g] : 0;
+        const unsigned long long a1 = in ? adler[2 * g] : 0ull, a2 = in ? adler[2 * g + 1] : 0ull;
         int incl = v;
+        unsigned long long incl1 = a1;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
+            const unsigned long long up1 = __shfl_up(incl1, d);
+            if (lane >= d) { incl += up; incl1 += up1; }
         }
-        if (lane == 63) wsum[wave] = incl;
+        if (lane == 63) { wsum[wave] = incl; wsum1[wave] = incl1; }
         __syncthreads();
         int before = 0, total = 0;
+        unsigned long long before1 = 0, total1 = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { before += w < wave ? wsum[w] : 0; total += wsum[w]; }
-        if (i < segs_per_img) segoff[(size_t)img * segs_per_img + i] = carry + before + incl - v;
+        for (int w = 0; w < 4; ++w) {
+            before += w < wave ? wsum[w] : 0; total += wsum[w];
+            before1 += w < wave ? wsum1[w] : 0ull; total1 += wsum1[w];
+        }
+        if (in) segoff[g] = carry + before + incl - v;
+        const unsigned long long rows = in ? (unsigned long long)min(kRowsPerSeg, H - i * kRowsPerSeg) : 0ull;
+        const unsigned long long Ls = rows * (unsigned long long)(W + 1);
+        const unsigned long long prefix1 = (carry1 + before1 + incl1 - a1) % kAdlerMod;        // S1 of all earlier segments
+        unsigned long long term = in ? (a2 + (Ls % kAdlerMod) * prefix1 + Ls) % kAdlerMod : 0ull;   // + L_s: the leading 1 of A
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) term += __shfl_xor(term, d);
+        __syncthreads();                                // wsum / wsum1 have been read
+        if (lane == 0) wterm[wave] = term;
+        __syncthreads();
+        bsum += (wterm[0] + wterm[1]) + (wterm[2] + wterm[3]);
         carry += total;
+        carry1 += total1;
         __syncthreads();
     }
     if (tid == 0) {
-        // Adler-32 of the concatenation: A = 1 + sum of bytes; B = sum of the running A's
-        unsigned long long A = 1, B = 0;
-        for (int s = 0; s < segs_per_img; ++s) {
-            const int rows = min(kRowsPerSeg, H - s * kRowsPerSeg);
-            const unsigned long long L = (unsigned long long)rows * (unsigned long long)(W + 1);
-            B = (B + (L % kAdlerMod) * A + adler[2 * ((size_t)img * segs_per_img + s) + 1]) % kAdlerMod;
-            A = (A + adler[2 * ((size_t)img * segs_per_img + s)]) % kAdlerMod;
-        }
+        const unsigned long long A = (1ull + carry1) % kAdlerMod, B = bsum % kAdlerMod;
         const long long need = (long long)carry + 6;
         uint8_t* o = out + (size_t)img * out_stride;
         if (need <= out_stride) {
