@@ -7,8 +7,10 @@
 //                          2x2 chroma box filter in registers (row partner by wave shuffle), the two 8-point DCT
 //                          passes through LDS (one row / column per lane), quantisation, 16-byte coalesced stores of
 //                          the six zigzag-ordered coefficient blocks            (3 B/px read, 3 B/px written)
-//   jpeg_entropy_kernel    one lane per restart interval: Huffman coding with byte stuffing into a private scratch
-//                          segment; DC prediction restarts with the interval, which is what makes lanes independent
+//   jpeg_entropy_wave_kernel  one wave per restart interval, a lane per coefficient: zero runs from the ballot of
+//                          non-zeros, per-lane bit strings placed by a wave scan into an LDS bit buffer, byte stuffing
+//                          into a private scratch segment; DC prediction restarts with the interval, which is what
+//                          makes the waves independent (jpeg_entropy_kernel: one lane per interval, for long intervals)
 //   jpeg_offsets_kernel    per image: exclusive scan of the segment lengths, EOI marker, total length
 //   jpeg_gather_kernel     one wave per segment: scratch -> its final position in the image's scan
 // Bit-exact contract: oracle/c/jpeg_oracle.c (itself byte-identical to libjpeg-turbo via Pillow).
@@ -287,6 +289,123 @@ __global__ __launch_bounds__(64) void jpeg_entropy_kernel(const int16_t* __restr
     seglen[t] = o.n;
 }
 
+// The same coding with one WAVE per restart interval (used for intervals of up to kWaveRestartMax MCUs): a lane per
+// coefficient of a block.  The zero run in front of a non-zero coefficient comes from the ballot of non-zeros, every lane
+// builds its own bit string ([ZRL..] code value-bits, lane 0 the DC difference, the last non-zero lane also the EOB), a
+// wave scan of the lengths gives its bit offset, and the strings are OR-ed into a zeroed LDS bit buffer.  Byte stuffing
+// is a second pass over that buffer: 64 bytes at a time, the 0xFF bytes in front of a lane counted by ballot + popcount.
+constexpr int kWaveRestartMax = 8;
+constexpr int kRawWordsPerBlock = 54;        // 64 coefficients x 27 bits at most = 216 bytes, before stuffing
+
+__device__ __forceinline__ void deposit(unsigned* buf, int o, unsigned long long str, int len) {   // MSB first at bit offset o
+    const int w = o >> 5, shift = 64 - (o & 31) - len;          // the 64-bit window over words w, w+1
+    unsigned long long hi;
+    unsigned lo = 0;
+    if (shift >= 0) hi = str << shift;
+    else { hi = str >> (-shift); lo = (unsigned)(str << (32 + shift)); }
+    const unsigned h1 = (unsigned)(hi >> 32), h0 = (unsigned)hi;
+    if (h1) atomicOr(&buf[w], h1);
+    if (h0) atomicOr(&buf[w + 1], h0);
+    if (lo) atomicOr(&buf[w + 2], lo);
+}
+
+__global__ __launch_bounds__(256) void jpeg_entropy_wave_kernel(const int16_t* __restrict__ coef, int mcus_per_img, int restart,
+                                                                int segs_per_img, int total_segs, int segcap, int words_per_wave,
+                                                                uint8_t* __restrict__ scratch, int* __restrict__ seglen) {
+    extern __shared__ unsigned raw[];
+    __shared__ uint32_t huff[4][256];
+    for (int i = threadIdx.x; i < 1024; i += 256) huff[i >> 8][i & 255] = kHuffDev[i >> 8].e[i & 255];
+    __syncthreads();                                   // the only block-wide barrier: waves are independent from here on
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= total_segs) return;
+    unsigned* buf = raw + wave * words_per_wave;
+    for (int i = lane; i < words_per_wave; i += 64) buf[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int img = t / segs_per_img, s = t - img * segs_per_img;
+    const int m0 = s * restart, m1 = min(m0 + restart, mcus_per_img);
+    const int16_t* c = coef + ((size_t)img * mcus_per_img + m0) * 384;
+    const int nblocks = (m1 - m0) * 6;
+    int bitpos = 0, pred[3] = {0, 0, 0};
+    short v = c[lane];
+    for (int bi = 0; bi < nblocks; ++bi) {
+        const short vnext = c[(bi + 1 < nblocks ? bi + 1 : bi) * 64 + lane];      // prefetch the next block
+        const int b = bi % 6, ci = b < 4 ? 0 : b - 3;
+        const uint32_t* dc = huff[b < 4 ? 0 : 2];
+        const uint32_t* ac = huff[b < 4 ? 1 : 3];
+        const int dcv = __builtin_amdgcn_readlane((int)v, 0);
+        const int diff = dcv - pred[ci];
+        pred[ci] = dcv;
+        const unsigned long long nzmask = __ballot(v != 0) & ~1ull;              // non-zero AC coefficients
+        const int val = lane == 0 ? diff : (int)v;
+        const int a = val < 0 ? -val : val;
+        const int nb = 32 - __clz(a);
+        const unsigned vb = (unsigned)(val < 0 ? val - 1 : val) & ((1u << nb) - 1u);
+        unsigned long long str = 0;
+        int len = 0;
+        if (lane == 0) {
+            const uint32_t e = dc[nb];
+            str = ((unsigned long long)(e >> 5) << nb) | vb;
+            len = (int)(e & 31u) + nb;
+        } else if (v != 0) {
+            const unsigned long long lower = nzmask & ((1ull << lane) - 1ull);
+            const int prevpos = lower ? 63 - __clzll((long long)lower) : 0;
+            const int run = lane - prevpos - 1;
+            const uint32_t z = ac[0xF0], e = ac[((run & 15) << 4) + nb];
+            for (int k = run >> 4; k > 0; --k) { str = (str << (z & 31u)) | (z >> 5); len += (int)(z & 31u); }
+            const int cl = (int)(e & 31u) + nb;
+            str = (str << cl) | ((unsigned long long)(e >> 5) << nb) | vb;
+            len += cl;
+        }
+        const int lastnz = nzmask ? 63 - __clzll((long long)nzmask) : 0;         // uniform; 0 = no AC coefficient at all
+        if (lastnz != 63 && lane == lastnz) {                                      // end of block
+            const uint32_t e = ac[0];
+            str = (str << (e & 31u)) | (e >> 5);
+            len += (int)(e & 31u);
+        }
+        int incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (len) deposit(buf, bitpos + incl - len, str, len);
+        bitpos += __builtin_amdgcn_readlane(incl, 63);
+        v = vnext;
+    }
+    if ((bitpos & 7) && lane == 0) {                                               // pad the last byte with ones
+        const int pad = 8 - (bitpos & 7);
+        deposit(buf, bitpos, (1ull << pad) - 1ull, pad);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int nbytes = (bitpos + 7) >> 3;
+    uint8_t* dst = scratch + (size_t)t * segcap;
+    int outpos = 0;
+    for (int j0 = 0; j0 < nbytes; j0 += 64) {                                      // byte stuffing: 0xFF -> 0xFF 0x00
+        const int j = j0 + lane;
+        const bool valid = j < nbytes;
+        const unsigned byte = valid ? (buf[j >> 2] >> (24 - 8 * (j & 3))) & 255u : 0u;
+        const bool ff = valid && byte == 255u;
+        const unsigned long long m = __ballot(ff);
+        if (valid) {
+            const int pos = outpos + lane + __popcll(m & ((1ull << lane) - 1ull));
+            dst[pos] = (uint8_t)byte;
+            if (ff) dst[pos + 1] = 0;
+        }
+        outpos += min(64, nbytes - j0) + __popcll(m);
+    }
+    if (lane == 0) {
+        if (s != segs_per_img - 1) {                                               // RSTm in front of the next interval
+            dst[outpos] = 0xFF;
+            dst[outpos + 1] = (uint8_t)(0xD0 + (s & 7));
+            outpos += 2;
+        }
+        seglen[t] = outpos;
+    }
+}
+
 // One block per image: exclusive scan of its segment lengths; EOI marker and the total (negative when it does not fit).
 __global__ __launch_bounds__(256) void jpeg_offsets_kernel(const int* __restrict__ seglen, int segs_per_img,
                                                            int* __restrict__ segoff, int* __restrict__ lengths,
@@ -437,8 +556,14 @@ int gsa_jpeg_encode(void* stream, int32_t n, int32_t H, int32_t W, const uint8_t
     const int total_mcus = n * g.mcus_per_img, total_segs = n * g.segs_per_img;
     const int tgrid = (total_mcus + 3) / 4 < 8192 ? (total_mcus + 3) / 4 : 8192;
     hipLaunchKernelGGL(jpeg_transform_kernel, dim3(tgrid), dim3(256), 0, s, rgb, H, W, g.mcus_x, g.mcus_per_img, total_mcus, q, coef);
-    hipLaunchKernelGGL(jpeg_entropy_kernel, dim3((total_segs + 63) / 64), dim3(64), 0, s, coef, g.mcus_per_img, restart,
-                       g.segs_per_img, total_segs, g.segcap, scratch, seglen);
+    if (restart <= kWaveRestartMax) {
+        const int words = restart * 6 * kRawWordsPerBlock + 4;
+        hipLaunchKernelGGL(jpeg_entropy_wave_kernel, dim3((total_segs + 3) / 4), dim3(256), 4 * words * sizeof(unsigned), s, coef,
+                           g.mcus_per_img, restart, g.segs_per_img, total_segs, g.segcap, words, scratch, seglen);
+    } else {
+        hipLaunchKernelGGL(jpeg_entropy_kernel, dim3((total_segs + 63) / 64), dim3(64), 0, s, coef, g.mcus_per_img, restart,
+                           g.segs_per_img, total_segs, g.segcap, scratch, seglen);
+    }
     hipLaunchKernelGGL(jpeg_offsets_kernel, dim3(n), dim3(256), 0, s, seglen, g.segs_per_img, segoff, lengths, out,
                        (long long)out_stride);
     hipLaunchKernelGGL(jpeg_gather_kernel, dim3((total_segs + 3) / 4), dim3(256), 0, s, scratch, seglen, segoff,

@@ -14,8 +14,8 @@ from ._runtime import current_stream_ptr
 _FUNCS = None
 
 DEFAULT_QUALITY = 95     # cv2.imwrite's default JPEG quality (the reference passes none)
-DEFAULT_RESTART = 2      # MCUs (16x16 px) per restart interval: 2048 independent lanes per 1024^2 image; measured on
-#                          8 FFHQ-size images: restart 1 -> 0.14 ms (+1.5 % bytes), 2 -> 0.21 ms (+0.5 %), 4 -> 0.36 ms
+DEFAULT_RESTART = 4      # MCUs (16x16 px) per restart interval = one wave of the entropy-coding kernel: 1024 independent
+#                          waves per 1024^2 image, +0.25 % bytes; measured on 8 FFHQ-size images: 0.09 ms for restart 1, 2 or 4
 
 
 def _api():
