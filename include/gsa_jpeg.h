@@ -37,7 +37,8 @@ int64_t gsa_jpeg_workspace_bytes(int32_t n, int32_t H, int32_t W, int32_t restar
 int64_t gsa_jpeg_max_scan_bytes(int32_t H, int32_t W, int32_t restart);
 
 /* Encode n RGB images (n,H,W,3) u8, H and W multiples of 16 (every StyleGAN resolution >= 16 px is), 16-byte
- * aligned.  restart = MCUs (16x16 px) per restart interval, 1..65535.  Image i's scan + EOI marker goes to
+ * aligned.  restart = MCUs (16x16 px) per restart interval, 1..65535 (up to 8: one wave per interval, the fast path;
+ * longer intervals are coded by one lane each).  Image i's scan + EOI marker goes to
  * out + i*out_stride and lengths[i] = its byte count; the file is gsa_jpeg_header()'s bytes followed by those.
  * If an image needs more than out_stride bytes, lengths[i] = -(bytes needed) and its output is truncated. */
 int gsa_jpeg_encode(void* stream, int32_t n, int32_t H, int32_t W, const uint8_t* rgb, int32_t quality, int32_t restart,
