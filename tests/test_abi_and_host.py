@@ -228,3 +228,20 @@ def test_annotation_sample_files(tmp_path):
     Image.fromarray(np.full((2, 3, 3), 10, np.uint8), "RGB").save(tmp_path / "img_000007.jpg")
     mask, img2, f2 = A.load_sample(str(tmp_path), 7)
     assert mask.tolist() == [[-1, -1, 0], [0, 1, 1]] and img2.shape == (2, 3, 3) and len(f2) == 3
+
+
+def test_bench_reads_every_committed_pmc_summary():
+    """bench.py takes `roofline.traffic` from profiles/*_pmc_summary.json: every committed summary must be in the
+    layout it reads (a list of records keyed "kernel"), and an unknown kernel gives None, never an exception."""
+    import glob
+    import json
+    import bench
+    paths = glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))
+    assert paths
+    for path in paths:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+        assert isinstance(kernels, list) and all("kernel" in k and "hbm_bytes_per_launch" in k for k in kernels), path
+        hit = bench.pmc_traffic(kernels[0]["kernel"])
+        assert hit is not None and hit["bytes_per_launch"] > 0
+    assert bench.pmc_traffic("no such kernel") is None
