@@ -189,7 +189,7 @@ def main():
     torch.cuda.synchronize()
     entries = ctx.profile_entries()
     ctx.profile_enable(0)
-    ctx.set_overlap(64)
+    ctx.set_overlap(-1)        # back to the default (by batch size)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

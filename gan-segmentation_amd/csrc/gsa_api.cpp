@@ -118,7 +118,7 @@ struct gsa_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int bf16 = 0;                 // gsa_set_precision: 1 = bf16 MFMA operands (fixed once weights are committed)
     int dbg = 0;                  // GSA_DBG, read once at gsa_create (only the diagnostic build looks at it)
-    int side_levels = kMaxLevels; // decoder levels 0..side_levels-1 (all but the last) go to the side stream (GSA_SIDE_LEVELS)
+    int side_levels = -1;         // decoder levels 0..side_levels-1 go to the side stream; -1 = by batch size (GSA_SIDE_LEVELS)
 
     // profiling
     int prof = 0;
@@ -1030,11 +1030,15 @@ int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const floa
     const float* fsrc[kMaxLevels];
     const Aff* faff[kMaxLevels];
     for (int l = 0; l < c->nlev; ++l) { fsrc[l] = c->x2[l]; faff[l] = c->aff2[l]; }
-    // Decoder level i only needs the generator feature of level i, so the decoder runs on a second
+    // Decoder level i only needs the generator feature of level i, so the decoder can run on a second
     // stream beside the synthesis of the higher levels (fork/join through events, no host
-    // synchronisation, graph-capturable): its short, latency-bound low-resolution kernels hide behind
-    // the large synthesis kernels and the tails of either side are filled by the other (+3.6 % measured).
-    const int ns = c->side_levels < 0 ? 0 : (c->side_levels > c->d_n - 1 ? c->d_n - 1 : c->side_levels);
+    // synchronisation, graph-capturable): its short, latency-bound low-resolution kernels then hide behind
+    // the synthesis kernels and the tails of either side are filled by the other.
+    // Measured on MI355X: up to 4 samples per call the chip has room beside the synthesis kernels
+    // (+4 % at 4, +8 % at 2, +15 % at 1 for FFHQ); from 8 samples on every large kernel is persistent and fills the
+    // chip, and a second stream only costs (-0.7 % FFHQ batch 8, -1.6..-3.9 % bedrooms batch 64 / 16).
+    const int want = c->side_levels < 0 ? (n <= 4 ? c->d_n - 1 : 0) : c->side_levels;
+    const int ns = want > c->d_n - 1 ? c->d_n - 1 : want;
     if (ns > 0) {
         HIP_TRY(hipEventRecord(c->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
@@ -1080,7 +1084,7 @@ int gsa_segmentation_eval(gsa_ctx* c, void* stream, int32_t n, int32_t classes, 
 
 int gsa_set_overlap(gsa_ctx* c, int32_t levels) {
     if (!c) return GSA_ERR_INVALID;
-    c->side_levels = levels < 0 ? 0 : levels;
+    c->side_levels = levels < 0 ? -1 : levels;
     return GSA_OK;
 }
 
