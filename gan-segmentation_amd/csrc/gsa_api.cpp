@@ -1034,10 +1034,11 @@ int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const floa
     // stream beside the synthesis of the higher levels (fork/join through events, no host
     // synchronisation, graph-capturable): its short, latency-bound low-resolution kernels then hide behind
     // the synthesis kernels and the tails of either side are filled by the other.
-    // Measured on MI355X: up to 4 samples per call the chip has room beside the synthesis kernels
-    // (+4 % at 4, +8 % at 2, +15 % at 1 for FFHQ); from 8 samples on every large kernel is persistent and fills the
-    // chip, and a second stream only costs (-0.7 % FFHQ batch 8, -1.6..-3.9 % bedrooms batch 64 / 16).
-    const int want = c->side_levels < 0 ? (n <= 4 ? c->d_n - 1 : 0) : c->side_levels;
+    // Measured on MI355X: below 8 samples per call the chip has room beside the synthesis kernels
+    // (FFHQ fp32: +15 % at 1, +8 % at 2, +4 % at 4, +3 % at 6), and in bf16 mode at every batch size (kernels 2-3x
+    // shorter: +5 % at 8, +7 % at 16); in fp32 from 8 samples on every large kernel is persistent and fills the chip,
+    // and a second stream only costs (-0.7 % FFHQ batch 8, -1.6..-3.9 % bedrooms batch 64 / 16).
+    const int want = c->side_levels < 0 ? ((c->bf16 || n < 8) ? c->d_n - 1 : 0) : c->side_levels;
     const int ns = want > c->d_n - 1 ? c->d_n - 1 : want;
     if (ns > 0) {
         HIP_TRY(hipEventRecord(c->ev_fork, s));

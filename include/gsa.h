@@ -124,7 +124,8 @@ int gsa_generate(gsa_ctx* ctx, void* stream, int32_t n, const float* z,
 
 /* gsa_generate runs the decoder on a second HIP stream beside the synthesis of the higher
  * resolutions (fork/join through events).  `levels` = number of decoder levels placed there; negative = the default:
- * all but the last for calls of up to 4 samples, none from there on (the large kernels then fill the chip on their own);
+ * all but the last in bf16 mode and for fp32 calls of fewer than 8 samples, none for larger fp32 calls (the large
+ * kernels then fill the chip on their own);
  * 0 = everything on the caller's stream, used by bench.py's serialized roofline pass so that kernel durations are
  * not stretched by concurrent kernels. */
 int gsa_set_overlap(gsa_ctx* ctx, int32_t levels);
