@@ -101,6 +101,97 @@ def cpu_baseline(gan, seconds_budget=25.0):
                       % (gan, 2 ** mr, len(times))}
 
 
+def pair_digest(img, mask):
+    """SHA-256 of one sample's (image, mask) bytes -- the digest tests/golden/bench_outputs.json holds for the C
+    oracle's output on these very inputs (tests/golden/make_bench_hash.py)."""
+    import hashlib
+    return hashlib.sha256(img.contiguous().cpu().numpy().tobytes() + mask.contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+def golden_digests(gan, batch):
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "bench_outputs.json")) as f:
+            return json.load(f).get("%s_b%d" % (gan, batch), {}).get("samples")
+    except (OSError, ValueError):
+        return None
+
+
+def output_check(gan, batch, precision, img, mask):
+    """What the run produced, so that the line is not only a speed: digest of sample 0 and whether it equals the
+    oracle's (fp32, the batch sizes the golden file holds; bf16 mode is a stated tolerance, never bit equality)."""
+    out = {"sample0_sha256": pair_digest(img[0], mask[0]), "mask_mean": round(float(mask.float().mean().item()), 6)}
+    want = golden_digests(gan, batch) if precision == "fp32" else None
+    out["oracle_sha256"] = want[0] if want else None
+    out["matches_oracle"] = (out["sample0_sha256"] == want[0]) if want else None
+    return out
+
+
+def measure_secondary(gan, batch, precision, steps, warmup, dev):
+    """A short, separate measurement of another BASELINE.json configuration (own model, own context), reported under
+    `secondary` -- the headline fields stay those of configs[1]."""
+    import torch
+    from gan_segmentation_amd import weights as W
+    from gan_segmentation_amd.image_generator import ImageGenerator
+    mr = W.GAN_MAX_RES_LOG2[gan]
+    gcfg, dcfg = W.generator_config(mr), W.decoder_config(mr)
+    gp, dp = W.synthetic_generator_params(gcfg, seed=2), W.synthetic_decoder_params(dcfg, seed=3)
+    gen = ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[dev.index], batch_size=batch, precision=precision)
+    z, noise = W.synthetic_inputs(gcfg, batch, seed_z=1000, seed_noise=2000)
+    z = torch.from_numpy(z).to(dev)
+    noise = [torch.from_numpy(a).to(dev) for a in noise]
+    for _ in range(warmup):
+        img, mask = gen.generate_batch(z, noise)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        img, mask = gen.generate_batch(z, noise)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"workload": "stylegan-%s %d^2 synthesis + decoder, batch=%d, %s, 1 GPU" % (gan, 2 ** mr, batch, precision),
+           "value": round(batch * steps / dt, 2), "unit": "pairs/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(1e3 * dt / steps, 3), "dtype": "f32" if precision == "fp32" else "bf16",
+           "output": output_check(gan, batch, precision, img, mask)}
+    del gen
+    return res
+
+
+def measure_end_to_end(gen, B, steps, dev):
+    """The dataset rate beside the kernel-path rate: what `main.py generate` does per batch besides gsa_generate --
+    counter-based latents/noise drawn on the device (gsa_fill_inputs), the GPU JPEG + PNG encoders, the copy of the
+    compressed bytes to the host and the file writes (DatasetWriter into a temporary directory)."""
+    import shutil
+    import tempfile
+    import torch
+    from gan_segmentation_amd.dataset_writer import DatasetWriter
+    out = {}
+    for _ in range(2):
+        gen.generate_indexed(0, B, seed=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        gen.generate_indexed(k * B, B, seed=0)
+    torch.cuda.synchronize()
+    out["with_input_generation_pairs_per_s"] = round(B * steps / (time.perf_counter() - t0), 2)
+    tmp = tempfile.mkdtemp(prefix="gsa_bench_")
+    try:
+        with DatasetWriter(tmp, gpu_jpeg=True, gpu_png=True) as w:
+            for k in range(2):
+                w.submit(*gen.generate_indexed(k * B, B, seed=0), k * B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with DatasetWriter(tmp, gpu_jpeg=True, gpu_png=True) as w:
+            for k in range(steps):
+                w.submit(*gen.generate_indexed(k * B, B, seed=0), k * B)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["to_disk_pairs_per_s"] = round(B * steps / dt, 2)
+        out["to_disk_files"] = len(os.listdir(tmp))
+        out["sink"] = "img_%06d.jpg + mask_%06d.png in a temporary directory (GPU JPEG/PNG encoders, host threads frame and write)"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,8 +203,12 @@ def main():
                     help="bf16 = bf16 MFMA operands, fp32 accumulate/statistics (BASELINE.json configs[4]); "
                          "the headline metric is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of configs[3]/[4] and the end-to-end rate")
+    ap.add_argument("--allow-blocking", action="store_true",
+                    help="N>1: fall back to the blocking gather if the overlapped one is refused (default: exit non-zero)")
     ap.add_argument("--layers", action="store_true", help="per-layer kernel breakdown on stderr")
     args = ap.parse_args()
+    t_proc = time.perf_counter()
 
     import torch
     import torch.distributed as dist
@@ -145,21 +240,25 @@ def main():
     # the pairs of every rank land on rank 0 through ONE gather per batch, double buffered so that the transfer
     # of batch k overlaps the kernels of batch k+1 (dist.PairGatherer); at N=1 the outputs simply stay in HBM
     gat = gdist.PairGatherer(B, 2 ** mr, gcfg["channels"], device=dev, dst=0, depth=2)
-    state = {"k": 0}
+    state = {"k": 0, "gather": "overlapped" if world > 1 else "none"}
 
     def step():
         slot = state["k"] & 1
         state["k"] += 1
-        if state.get("blocking"):            # fallback (see below): the plain blocking gather
+        if state["gather"] == "blocking":    # fallback (see below): the plain blocking gather
             gdist.gather_pairs(*gen.generate_batch(z, noise))
             return
         gat.wait(slot)                       # the gather that last read this buffer (two batches ago)
         gen.generate_batch(z, noise, out=gat.buffers(slot))
         try:
             gat.submit(slot)
-        except Exception as e:               # an RCCL build without async gather into views: keep the run alive, say so
+        except Exception as e:               # an RCCL build without async gather into views
+            if not args.allow_blocking:
+                print("bench: the overlapped gather was refused (%s); rerun with --allow-blocking to time the blocking "
+                      "gather instead" % e, file=sys.stderr, flush=True)
+                raise SystemExit(3)
             print("bench: overlapped gather failed (%s); using the blocking gather" % e, file=sys.stderr, flush=True)
-            state["blocking"] = True
+            state["gather"] = "blocking"
             gdist.gather_pairs(*gat.buffers(slot))
 
     def fence():
@@ -168,9 +267,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_setup = time.perf_counter() - t_proc
+    t1 = time.perf_counter()
     for _ in range(args.warmup):
         step()
     fence()
+    if world > 1:       # a rank that fell back during warm-up takes every rank with it (the collectives must match)
+        flag = torch.tensor([1 if state["gather"] == "blocking" else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            state["gather"] = "blocking"
+    t_warm = time.perf_counter() - t1
     # ---- timed region: EXACTLY K steps (no per-launch events here: 2 event packets around each of the
     # ~130 launches of a step cost ~5 % of the step)
     t0 = time.perf_counter()
@@ -178,9 +285,11 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    last_slot = (state["k"] - 1) & 1
     # ---- roofline pass (untimed): the same K steps with every launch bracketed by HIP events on its
     # stream, and with the decoder/synthesis stream overlap off, so that a kernel's duration is its own
     # and not stretched by the kernel running beside it
+    t1 = time.perf_counter()
     ctx.set_overlap(0)
     ctx.profile_enable(2 if args.layers else 1)
     ctx.profile_reset()
@@ -190,6 +299,7 @@ def main():
     entries = ctx.profile_entries()
     ctx.profile_enable(0)
     ctx.set_overlap(-1)        # back to the default (by batch size)
+    t_prof = time.perf_counter() - t1
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -201,6 +311,9 @@ def main():
         entries.sort(key=lambda e: -e["ms"])
         top = entries[0]
         kms = sum(e["ms"] for e in entries)
+        # FLOP the kernels really execute (the sub-pixel form of nearest-x2 + conv3x3 needs 4 taps instead of 9 and the
+        # 1x1 shortcuts run at input resolution): what the MFMA roofline of the whole step is priced on
+        exec_gflop = sum(e["flops"] for e in entries) / args.steps / B / 1e9
         ach = top["flops"] / (top["ms"] * 1e-3) / 1e12 if top["ms"] > 0 else 0.0
         tr = pmc_traffic(top["name"])
         bound, peak, unit = "mfma", PEAK_FP32_TFLOPS, "TFLOP/s"
@@ -218,6 +331,8 @@ def main():
                     "algorithmic_bytes_per_launch": round(top["bytes"] / max(1, top["launches"])),
                     "traffic": tr["bytes_per_launch"] if tr else None,
                     "traffic_source": tr["source"] if tr else None}
+        mfma_peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS
+        out_img, out_mask = gat.buffers(last_slot) if state["gather"] != "blocking" else gen.generate_batch(z, noise)
         out = {
             "metric": "synthetic (image,mask) pairs/sec, %s-%d StyleGAN+decoder" % (args.gan.upper(), 2 ** mr),
             "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -228,20 +343,28 @@ def main():
                                    % (args.gan, 2 ** mr, dcfg["num_classes"], B,
                                       "fp32 (BASELINE.json configs[1])" if args.precision == "fp32" else
                                       "bf16 MFMA operands, fp32 accumulate and statistics (BASELINE.json configs[4])"),
-                       "global_batch": world * B, "parallelism": "dp%d" % world},
+                       "global_batch": world * B, "parallelism": "dp%d" % world,
+                       # which exchange the timed steps contained: none (1 GPU), the overlapped asynchronous gather
+                       # (dist.PairGatherer) or the blocking fallback (--allow-blocking only)
+                       "gather": state["gather"]},
             "roofline": roofline,
             "whole_path": {
-                # reference FLOPs per second; priced against the f32 MFMA peak, or the dense bf16 MFMA
-                # peak in bf16 mode
+                # reference FLOPs per second against the f32 MFMA peak (dense bf16 peak in bf16 mode) -- and the
+                # FLOP the kernels execute after the sub-pixel rewrite, which is the roofline figure of the whole step
                 "tflops": round(GFLOP_PER_SAMPLE[args.gan] * value / 1e3, 2),
-                "mfma_peak_tflops": PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS,
-                "frac_of_mfma_peak": round(GFLOP_PER_SAMPLE[args.gan] * value / 1e3 / world /
-                                           (PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS), 4),
+                "mfma_peak_tflops": mfma_peak,
+                "frac_of_mfma_peak": round(GFLOP_PER_SAMPLE[args.gan] * value / 1e3 / world / mfma_peak, 4),
+                "reference_gflop_per_sample": GFLOP_PER_SAMPLE[args.gan],
+                "executed_gflop_per_sample": round(exec_gflop, 2),
+                "executed_tflops": round(exec_gflop * value / 1e3, 2),
+                "frac_of_mfma_peak_executed": round(exec_gflop * value / 1e3 / world / mfma_peak, 4),
                 "algorithmic_hbm_gbs": round(MB_PER_SAMPLE[args.gan] * value / 1e3, 1),
                 "hbm_frac_of_peak": round(MB_PER_SAMPLE[args.gan] * value / 1e3 / world / PEAK_HBM_GBS, 4),
                 "hbm_frac_of_measured_peak": round(MB_PER_SAMPLE[args.gan] * value / 1e3 / world / MEASURED_HBM_GBS, 4),
                 "kernel_ms_per_step": round(kms / args.steps, 3),
             },
+            # the bytes the timed configuration produced (rank 0, sample 0 of the last timed step) against the C oracle
+            "output": output_check(args.gan, B, args.precision, out_img, out_mask),
             "kernels": [{"name": e["name"], "ms_per_step": round(e["ms"] / args.steps, 3),
                          "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else 0.0,
                          "gbs": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 1) if e["ms"] > 0 else 0.0}
@@ -252,8 +375,22 @@ def main():
                 print("%-70s %8.3f ms/step %7.2f TF/s %8.1f GB/s" % (
                     e["name"], e["ms"] / args.steps, e["flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] else 0,
                     e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["ms"] else 0), file=sys.stderr)
+        wall = {"setup": round(t_setup, 2), "warmup": round(t_warm, 3), "timed": round(dt, 4), "profile_pass": round(t_prof, 3)}
+        if world == 1 and not args.no_secondary:
+            t1 = time.perf_counter()
+            out["end_to_end"] = measure_end_to_end(gen, B, max(4, min(args.steps, 20)), dev)
+            sec = []
+            if (args.gan, args.precision, B) != ("bedrooms", "fp32", 64):
+                sec.append(measure_secondary("bedrooms", 64, "fp32", 10, 2, dev))      # BASELINE.json configs[3]
+            if (args.gan, args.precision, B) != ("cars", "bf16", 4):
+                sec.append(measure_secondary("cars", 4, "bf16", 20, 3, dev))           # per-GPU share of configs[4]
+            out["secondary"] = sec
+            wall["secondary"] = round(time.perf_counter() - t1, 2)
         if world == 1 and not args.no_cpu_baseline:
+            t1 = time.perf_counter()
             out["cpu_baseline"] = cpu_baseline(args.gan)
+            wall["cpu_baseline"] = round(time.perf_counter() - t1, 2)
+        out["wall_s"] = wall
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

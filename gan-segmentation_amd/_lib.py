@@ -71,13 +71,13 @@ class Api:
             "decoder_set_param": (c.c_int, [vp, c.c_char_p, vp, i32, c.POINTER(c.c_int64)]),
             "decoder_commit": (c.c_int, [vp]),
             "reserve": (c.c_int, [vp, i32]),
-            "generator_forward": (c.c_int, [vp, vp, i32, vp, c.POINTER(vp), vp, vp, c.POINTER(vp)]),
-            "decoder_forward": (c.c_int, [vp, vp, i32, c.POINTER(vp), vp, vp]),
-            "generate": (c.c_int, [vp, vp, i32, vp, c.POINTER(vp), vp, vp]),
+            "generator_forward": (c.c_int, [vp, vp, i32, vp, c.POINTER(vp), i32, vp, vp, c.POINTER(vp), i32]),
+            "decoder_forward": (c.c_int, [vp, vp, i32, c.POINTER(vp), i32, vp, vp]),
+            "generate": (c.c_int, [vp, vp, i32, vp, c.POINTER(vp), i32, vp, vp]),
             "set_overlap": (c.c_int, [vp, i32]),
             "set_precision": (c.c_int, [vp, i32]),
             "segmentation_eval": (c.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
-            "fill_inputs": (c.c_int, [vp, vp, i32, c.c_uint64, c.c_uint64, vp, c.POINTER(vp)]),
+            "fill_inputs": (c.c_int, [vp, vp, i32, c.c_uint64, c.c_uint64, vp, c.POINTER(vp), i32]),
             "profile_enable": (c.c_int, [vp, i32]),
             "profile_collect": (c.c_int, [vp]),
             "profile_entry": (c.c_int, [vp, i32, c.POINTER(c.c_char_p), c.POINTER(c.c_double),
@@ -196,15 +196,15 @@ class Context:
     # -- forward calls: every tensor argument is a raw address (int) or None -------------
     def generator_forward(self, stream, n, z, noise, rgb=None, img=None, feats=None):
         fp = _ptr_array(feats) if feats is not None else None
-        self._check(self.api.generator_forward(self._h, stream, n, z, _ptr_array(noise), rgb, img, fp),
-                    "generator_forward")
+        self._check(self.api.generator_forward(self._h, stream, n, z, _ptr_array(noise), len(noise), rgb, img, fp,
+                                               len(feats) if feats is not None else 0), "generator_forward")
 
     def decoder_forward(self, stream, n, feats, logits=None, mask=None):
-        self._check(self.api.decoder_forward(self._h, stream, n, _ptr_array(feats), logits, mask),
+        self._check(self.api.decoder_forward(self._h, stream, n, _ptr_array(feats), len(feats), logits, mask),
                     "decoder_forward")
 
     def generate(self, stream, n, z, noise, img, mask):
-        self._check(self.api.generate(self._h, stream, n, z, _ptr_array(noise), img, mask), "generate")
+        self._check(self.api.generate(self._h, stream, n, z, _ptr_array(noise), len(noise), img, mask), "generate")
 
     def set_precision(self, precision):
         """"fp32" (default, bit-exact canonical path) or "bf16" (bf16 MFMA operands); before the weights are loaded."""
@@ -213,7 +213,8 @@ class Context:
 
     def fill_inputs(self, stream, n, seed, first_index, z=None, noise=None):
         self._check(self.api.fill_inputs(self._h, stream, n, int(seed) & (2 ** 64 - 1), int(first_index), z,
-                                         _ptr_array(noise) if noise is not None else None), "fill_inputs")
+                                         _ptr_array(noise) if noise is not None else None,
+                                         len(noise) if noise is not None else 0), "fill_inputs")
 
     def segmentation_eval(self, stream, n, classes, H, W, logits, labels, confusion, loss_fixed):
         self._check(self.api.segmentation_eval(self._h, stream, n, classes, H, W, logits, labels, confusion, loss_fixed),

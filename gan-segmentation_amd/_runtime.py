@@ -25,31 +25,27 @@ def to_device_f32(x, device):
 
 
 class DeviceModel:
-    """A ``gsa_ctx`` bound to one torch device and one arithmetic ("fp32" / "bf16" MFMA operands), shared by
-    Generator and Decoder objects that live on the same GPU (so the fused ``generate`` call sees both)."""
+    """ONE ``gsa_ctx`` on one torch device with one arithmetic ("fp32" / "bf16" MFMA operands).
 
-    _by_device = {}
+    Every ``Generator`` and every stand-alone ``Decoder`` owns its own DeviceModel, as the reference's gluon
+    blocks own their parameters (two generators in one process never see each other's weights or
+    configuration).  A decoder that is to run fused with a generator (``ImageGenerator.attach_decoder``) is
+    loaded into THAT generator's context, because ``gsa_generate`` hands the features over inside it."""
 
     def __init__(self, device_index, precision="fp32"):
         require_gpu()
         if precision not in _lib.PRECISIONS:
             raise _lib.GsaError("precision must be one of %s" % sorted(_lib.PRECISIONS))
-        self.device = torch.device("cuda", device_index)
+        if not 0 <= int(device_index) < torch.cuda.device_count():
+            raise _lib.GsaError("gpu id %r: this process sees %d HIP device(s)" % (device_index, torch.cuda.device_count()))
+        self.device = torch.device("cuda", int(device_index))
         self.precision = precision
-        self.ctx = _lib.Context(_lib.load_library(), device_index)
+        self.ctx = _lib.Context(_lib.load_library(), int(device_index))
         if precision != "fp32":
             self.ctx.set_precision(precision)
         self.reserved = 0
         self.generator_cfg = None
         self.decoder_cfg = None
-
-    @classmethod
-    def get(cls, device_index=0, precision="fp32"):
-        m = cls._by_device.get((device_index, precision))
-        if m is None:
-            m = cls(device_index, precision)
-            cls._by_device[(device_index, precision)] = m
-        return m
 
     def ensure_batch(self, n):
         if n > self.reserved:
@@ -59,3 +55,15 @@ class DeviceModel:
 
     def invalidate_workspace(self):
         self.reserved = 0
+
+
+def split_sizes(total, parts):
+    """Sizes of the contiguous slices a batch of ``total`` samples is cut into for ``parts`` devices
+    (``gluon.utils.split_and_load(even_split=False)``, reference image_generator.py:95): empty slices are dropped."""
+    from .dist import shard_bounds
+    out = []
+    for r in range(parts):
+        lo, hi = shard_bounds(total, parts, r)
+        if hi > lo:
+            out.append((r, lo, hi))
+    return out

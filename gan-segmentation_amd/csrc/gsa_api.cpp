@@ -852,7 +852,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 if (!B.has_conv1) {
                     pp.src = c->constant; pp.src_per_sample = 0; pp.blur = nullptr;
                 } else {
-                    ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
+                    ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device;
                     cp.src0 = c->x2[l - 1]; cp.aff0 = c->aff2[l - 1]; cp.C0 = Cin;
                     cp.Hs = R / 2; cp.Ws = R / 2; cp.H = R; cp.W = R;
                     cp.wpk = B.w1; cp.Cout = C; cp.out = c->t_raw;
@@ -876,7 +876,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 HIP_TRY(launch_post(pp, n, s));
                 prow = post_prow(R, R, C);
             } else {
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device;
                 cp.src0 = c->x1; cp.aff0 = c->aff1; cp.C0 = C;
                 cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
                 cp.wpk = B.w2; cp.Cout = C; cp.out = c->x2[l];
@@ -927,7 +927,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
         const double px = N * R * R;
         if (wait_levels) HIP_TRY(hipStreamWaitEvent(s, c->ev_level[i], 0));   // generator feature i is ready
         {   // cvt_block: conv3x3+bias -> BN -> LeakyReLU (Dropout is identity at inference)
-            ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
+            ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device;
             cp.src0 = fsrc[i]; cp.aff0 = faff ? faff[i] : nullptr; cp.C0 = d.I;
             cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
             cp.wpk = d.cvt_w; cp.Cout = d.F; cp.out = c->cvt[i];
@@ -940,7 +940,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             const int R2 = 2 * R;
             const double px2 = 4 * px;
             {   // ResBlock conv a (+ fused 1x1 shortcut) on nearest-x2(concat(prev, cvt))
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device;
                 if (i > s0) { cp.src0 = c->prev[i - 1]; cp.C0 = d.F; cp.src1 = c->cvt[i]; cp.C1 = d.F; }
                 else { cp.src0 = c->cvt[i]; cp.C0 = d.F; }
                 cp.Hs = R; cp.Ws = R; cp.up = 1; cp.H = R2; cp.W = R2;
@@ -962,7 +962,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 }
             }
             {   // ResBlock conv b, + shortcut
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device;
                 cp.src0 = c->ya[i]; cp.C0 = d.cs;
                 cp.Hs = R2; cp.Ws = R2; cp.H = R2; cp.W = R2;
                 cp.wpk = d.b_w; cp.Cout = d.cs; cp.out = c->prev[i];
@@ -989,20 +989,23 @@ static int check_batch(gsa_ctx* c, int n) {
     return GSA_OK;
 }
 
-int gsa_generator_forward(gsa_ctx* c, void* stream, int32_t n, const float* z, const float* const* noise, float* rgb,
-                          uint8_t* img, float* const* feats) {
+int gsa_generator_forward(gsa_ctx* c, void* stream, int32_t n, const float* z, const float* const* noise, int32_t num_noise,
+                          float* rgb, uint8_t* img, float* const* feats, int32_t num_feats) {
     if (!c) return GSA_ERR_INVALID;
     if (!c->g_ready) return fail(c, GSA_ERR_STATE, "gsa_generator_commit first");
     if (!z || !noise) return fail(c, GSA_ERR_INVALID, "z and noise must not be null");
+    if (num_noise != 2 * c->nlev) return fail(c, GSA_ERR_INVALID, "%d noise planes passed, this generator has %d", num_noise, 2 * c->nlev);
+    if (feats && num_feats != c->nlev) return fail(c, GSA_ERR_INVALID, "%d feature pointers passed, this generator yields %d", num_feats, c->nlev);
     if (int rc = check_batch(c, n)) return rc;
     HIP_TRY(hipSetDevice(c->device));
     return run_generator(c, (hipStream_t)stream, n, z, noise, rgb, img, feats);
 }
 
-int gsa_decoder_forward(gsa_ctx* c, void* stream, int32_t n, const float* const* feats, float* logits, uint8_t* mask) {
+int gsa_decoder_forward(gsa_ctx* c, void* stream, int32_t n, const float* const* feats, int32_t num_feats, float* logits, uint8_t* mask) {
     if (!c) return GSA_ERR_INVALID;
     if (!c->d_ready) return fail(c, GSA_ERR_STATE, "gsa_decoder_commit first");
     if (!feats) return fail(c, GSA_ERR_INVALID, "feats must not be null");
+    if (num_feats != c->d_n) return fail(c, GSA_ERR_INVALID, "%d feature pointers passed, this decoder takes %d", num_feats, c->d_n);
     if (int rc = check_batch(c, n)) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1017,10 +1020,12 @@ int gsa_decoder_forward(gsa_ctx* c, void* stream, int32_t n, const float* const*
     return run_decoder(c, s, n, fsrc, nullptr, logits, mask);
 }
 
-int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const float* const* noise, uint8_t* img, uint8_t* mask) {
+int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const float* const* noise, int32_t num_noise, uint8_t* img,
+                 uint8_t* mask) {
     if (!c) return GSA_ERR_INVALID;
     if (!c->g_ready || !c->d_ready) return fail(c, GSA_ERR_STATE, "commit both generator and decoder first");
     if (!z || !noise) return fail(c, GSA_ERR_INVALID, "z and noise must not be null");
+    if (num_noise != 2 * c->nlev) return fail(c, GSA_ERR_INVALID, "%d noise planes passed, this generator has %d", num_noise, 2 * c->nlev);
     if (c->d_n != c->nlev) return fail(c, GSA_ERR_INVALID, "decoder expects %d features, the generator yields %d", c->d_n, c->nlev);
     for (int l = 0; l < c->nlev; ++l)
         if (c->d_inch[l] != c->ch[l]) return fail(c, GSA_ERR_INVALID, "decoder in_channels[%d]=%d but the generator feature has %d", l, c->d_inch[l], c->ch[l]);
@@ -1053,10 +1058,13 @@ int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const floa
     return run_decoder(c, s, n, fsrc, faff, nullptr, mask, ns, -1, false);
 }
 
-int gsa_fill_inputs(gsa_ctx* c, void* stream, int32_t n, uint64_t seed, uint64_t first_index, float* z, float* const* noise) {
+int gsa_fill_inputs(gsa_ctx* c, void* stream, int32_t n, uint64_t seed, uint64_t first_index, float* z, float* const* noise,
+                    int32_t num_noise) {
     if (!c) return GSA_ERR_INVALID;
     if (!c->g_init) return fail(c, GSA_ERR_STATE, "gsa_generator_init first");
     if (n <= 0 || (!z && !noise)) return fail(c, GSA_ERR_INVALID, "gsa_fill_inputs: bad argument");
+    if (noise && num_noise != 2 * (c->gc.max_res_log2 - 1))
+        return fail(c, GSA_ERR_INVALID, "%d noise planes passed, this generator has %d", num_noise, 2 * (c->gc.max_res_log2 - 1));
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     if (z) HIP_TRY(launch_fill_normal(z, c->gc.latent_size, n, first_index, 0xFFFFu, seed, s));

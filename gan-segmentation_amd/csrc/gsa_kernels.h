@@ -19,6 +19,7 @@ constexpr double kStatScale2 = 1048576.0;    // 2^20: quad sums of squares
 enum Epilogue { EPI_RAW = 0, EPI_SYNTH = 1, EPI_DEC = 2 };
 
 struct ConvParams {
+    int device;      // HIP device of the launching context (per-device launch state in the launchers)
     // input: up to two NHWC sources concatenated on channels (C0 then C1), both multiples of 16
     const float* src0; const Aff* aff0; int C0;   // aff0 may be null (identity)
     const float* src1; int C1;                    // src1 may be null

@@ -24,6 +24,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 // wave priority during the MFMA phase of conv3x3_mfma (the wave multiplying wins the SIMD's issue slot over the wave
 // staging): +0.5-1 % on the step in A/B runs; the same in the stride-2 kernels measured -0.5 % and is not used
@@ -2169,6 +2170,35 @@ __global__ __launch_bounds__(256) void fill_normal_kernel(float* out, int per_sa
 // ========================================================================================
 // host-side launchers
 
+// ---- per-device launch state -------------------------------------------------------------
+// hipFuncSetAttribute, the CU count and the occupancy answers belong to ONE device: a process may hold contexts
+// on several GPUs (ImageGenerator(gpu_ids=[0, 1, ...]), reference image_generator.py:17), so every launcher keeps
+// one LaunchState per (kernel instantiation, device), and a mutex makes the first-use path safe for the "one
+// context per (device, host thread)" contract of include/gsa.h.
+constexpr int kMaxDevices = 64;
+struct LaunchState {
+    bool attr_done = false;
+    size_t occ_lds[8] = {0};
+    int occ_k[8] = {0}, occ_n = 0;
+};
+static std::mutex g_launch_mu;
+
+static int device_cus(int dev) {     // caller holds g_launch_mu
+    static int cus[kMaxDevices] = {0};
+    if (dev < 0 || dev >= kMaxDevices) return 256;
+    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
+    return cus[dev];
+}
+
+// first launch of `kern` on device `dev`: allow the full 160 KB of dynamic LDS
+template <class K>
+static hipError_t prepare_kernel(K kern, LaunchState& st) {
+    if (st.attr_done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) st.attr_done = true;
+    return e;
+}
+
 // ---- conv3x3 geometry selection --------------------------------------------------------
 // Candidates per output size, most efficient first; the first one that fills the chip
 // (>= 2 workgroups per CU) wins, otherwise the one with the most workgroups.
@@ -2224,30 +2254,28 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     const size_t lds = sizeof(float) * (NBUF * (TH + 2) * RS + wslots + (SC ? Q * TS : 0)) +
                        (p.aff0 ? sizeof(float4) * (NBUF == 2 ? 32 : p.C0) : 0);   // double-buffered form: 2 x 16 AdaIN entries
     auto kern = conv3x3_mfma<TH, TW, WM, WN, NT, EPI, SC, BF>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
+    static LaunchState states[kMaxDevices];
+    int num_cus = 0, wgs_per_cu = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        LaunchState& st = states[p.device];
+        hipError_t e = prepare_kernel(kern, st);
         if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    // resident workgroups per CU for this LDS footprint (a few distinct footprints per instantiation: cached)
-    static int num_cus = 0;
-    static size_t occ_lds[8];
-    static int occ_k[8], occ_n = 0;
-    int wgs_per_cu = 0;
-    for (int i = 0; i < occ_n; ++i)
-        if (occ_lds[i] == lds) wgs_per_cu = occ_k[i];
-    if (!wgs_per_cu) {
-        int dev = 0, k = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, reinterpret_cast<const void*>(kern), 64 * WM * WN, lds);
-        if (e != hipSuccess) return e;
-        wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
-        if (occ_n < 8) { occ_lds[occ_n] = lds; occ_k[occ_n] = wgs_per_cu; ++occ_n; }
-        if (getenv("GSA_VERBOSE"))
-            fprintf(stderr, "gsa: conv3x3_mfma<%d,%d,%d,%d,%d,%d,%d,%d> lds %zu B%s -> %d workgroups/CU\n", TH, TW, WM, WN, NT, EPI, (int)SC,
-                    (int)BF, lds, wres ? " (resident weights)" : "", k);
+        num_cus = device_cus(p.device);
+        // resident workgroups per CU for this LDS footprint (a few distinct footprints per instantiation: cached)
+        for (int i = 0; i < st.occ_n; ++i)
+            if (st.occ_lds[i] == lds) wgs_per_cu = st.occ_k[i];
+        if (!wgs_per_cu) {
+            int k = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, reinterpret_cast<const void*>(kern), 64 * WM * WN, lds);
+            if (e != hipSuccess) return e;
+            wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
+            if (st.occ_n < 8) { st.occ_lds[st.occ_n] = lds; st.occ_k[st.occ_n] = wgs_per_cu; ++st.occ_n; }
+            if (getenv("GSA_VERBOSE"))
+                fprintf(stderr, "gsa: conv3x3_mfma<%d,%d,%d,%d,%d,%d,%d,%d> lds %zu B%s -> %d workgroups/CU\n", TH, TW, WM, WN, NT, EPI, (int)SC,
+                        (int)BF, lds, wres ? " (resident weights)" : "", k);
+        }
     }
     ConvParams q = p;
     q.w_resident = wres ? 1 : 0;
@@ -2297,15 +2325,14 @@ static hipError_t launch_conv_ws_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int Q = NT, COUT_T = 16 * Q;
     const size_t lds = sizeof(float) * (2 * 18 * (18 * 16 + 8) + 2 * Q * 9 * 256 + 2 * 256 * COUT_T) + (p.aff0 ? 2 * sizeof(float4) * p.C0 : 0);
     auto kern = conv3x3_ws<NT, EPI>;
-    static bool attr_done = false;
-    static int num_cus = 0;
-    if (!attr_done) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
+    static LaunchState states[kMaxDevices];
+    int num_cus = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        hipError_t e = prepare_kernel(kern, states[p.device]);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        num_cus = device_cus(p.device);
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     ConvParams q = p;
@@ -2369,11 +2396,12 @@ static hipError_t launch_subpixel_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int COUT_T = 16 * NT, TS = BF ? 128 : 256;
     const size_t lds = sizeof(float) * (10 * (10 * (BF ? 8 : 16) + (BF ? 4 : 8)) + NT * 16 * TS + (SC ? NT * TS : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
     auto kern = subpixel_mfma<NT, EPI, SC, BF>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
+    static LaunchState states[kMaxDevices];
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        hipError_t e = prepare_kernel(kern, states[p.device]);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     ConvParams q = p;
     q.tiles_x = p.W / 16;
@@ -2389,15 +2417,14 @@ static int subpixel_res_kb(const ConvParams& p);
 template <int NT, int EPI, bool SC, bool BF, int KB>
 static hipError_t launch_subpixel_res_k(const ConvParams& p, int n, size_t lds, hipStream_t s) {
     auto kern = subpixel_res<NT, EPI, SC, BF, KB, false>;
-    static bool attr_done = false;
-    static int num_cus = 0;
-    if (!attr_done) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
+    static LaunchState states[kMaxDevices];
+    int num_cus = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        hipError_t e = prepare_kernel(kern, states[p.device]);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        num_cus = device_cus(p.device);
     }
     ConvParams q = p;
     q.tiles_x = p.W / 16;
@@ -2413,11 +2440,12 @@ static hipError_t launch_subpixel_res_k(const ConvParams& p, int n, size_t lds, 
 template <int NT, int EPI, bool SC, bool BF>
 static hipError_t launch_subpixel_wst_t(const ConvParams& p, int n, size_t lds, int wgs_per_g, hipStream_t s) {
     auto kern = subpixel_res<NT, EPI, SC, BF, 1, true>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
+    static LaunchState states[kMaxDevices];
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        hipError_t e = prepare_kernel(kern, states[p.device]);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     ConvParams q = p;
     q.tiles_x = p.W / 16;
@@ -2431,10 +2459,10 @@ static hipError_t launch_subpixel_wst_t(const ConvParams& p, int n, size_t lds, 
 // Streamed form: LDS bytes and workgroups per channel group, or 0 when it does not pay (fewer than 2 tiles per half)
 static size_t subpixel_wst_lds(const ConvParams& p, int ct, bool sc, int n, int* wgs_per_g) {
     static const bool enabled = !(getenv("GSA_SUBWST") && atoi(getenv("GSA_SUBWST")) == 0);
-    static int num_cus = 0;
-    if (!num_cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) num_cus = 256;
+    int num_cus;
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        num_cus = device_cus(p.device);
     }
     if (!enabled || p.Cout % ct) return 0;
     const int ts = p.bf16 ? 128 : 256, px = p.bf16 ? 8 : 16, rs = 10 * px + (p.bf16 ? 4 : 8);

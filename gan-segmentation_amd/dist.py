@@ -21,6 +21,13 @@ def shard_bounds(total, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def env_ranks():
+    """(rank, world, local_rank) from the torchrun environment WITHOUT creating a process group: all a path
+    needs whose ranks never talk to each other (``main.py generate`` writing files: ``shard_bounds`` only)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

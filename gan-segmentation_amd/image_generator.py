@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import weights as _weights
-from ._runtime import DeviceModel, current_stream_ptr, to_device_f32
+from ._runtime import current_stream_ptr, split_sizes, to_device_f32
 from .networks_seg import Decoder
 from .networks_stylegan import Generator
 
@@ -32,19 +32,24 @@ class ImageGenerator:
         if len(gpu_ids) == 0:
             raise RuntimeError("the MI355X path has no CPU context: pass at least one gpu id "
                                "(the reference falls back to mx.cpu(), image_generator.py:17)")
-        if len(gpu_ids) > 1:
-            raise RuntimeError("one process drives one GPU; shard batches across ranks with "
-                               "gan_segmentation_amd.dist (one process per GPU over RCCL)")
-        self.ctx = gpu_ids
+        self.ctx = gpu_ids      # the reference's device list (image_generator.py:17): one weight replica per entry
         self.precision = precision
         self.cfg = self._get_config(max_res_log2=self.max_res_log2)
-        self.netG = self._get_G(self.cfg, gpu_ids[0])
         stylegan_name = "stylegan-%s.params" % gan
-        self.netG.load_parameters(os.path.join(gan_dir, stylegan_name), ignore_extra=True)
+        from . import params as _params
+        tensors = _params.load_params(os.path.join(gan_dir, stylegan_name))     # read once, loaded into every replica
+        self._gens = []
+        for dev in gpu_ids:
+            g = self._get_G(self.cfg, dev)
+            g.load_parameters(tensors, ignore_extra=True)
+            self._gens.append(g)
+        self.netG = self._gens[0]
         self._decoder = None
+        self._decoders = []
         self._rng = torch.Generator(device="cpu")
         self._rng.manual_seed(seed)
-        self.netG.seed(seed)
+        for g in self._gens:
+            g.seed(seed)
 
     @classmethod
     def from_params(cls, gcfg, gparams, dcfg=None, dparams=None, gpu_ids=(0,), batch_size=4,
@@ -58,14 +63,20 @@ class ImageGenerator:
         self.ctx = list(gpu_ids)
         self.cfg = dict(gcfg)
         self.precision = precision
-        self.netG = Generator(self.cfg, device=self.ctx[0], precision=precision)
-        self.netG.load_parameters(gparams)
+        self._gens = []
+        for dev in self.ctx:
+            g = Generator(self.cfg, device=dev, precision=precision)
+            g.load_parameters(gparams)
+            self._gens.append(g)
+        self.netG = self._gens[0]
         self._decoder = None
+        self._decoders = []
         if dcfg is not None:
             self.attach_decoder(dcfg, dparams)
         self._rng = torch.Generator(device="cpu")
         self._rng.manual_seed(seed)
-        self.netG.seed(seed)
+        for g in self._gens:
+            g.seed(seed)
         return self
 
     def _get_G(self, config, device):
@@ -75,16 +86,23 @@ class ImageGenerator:
         return _weights.generator_config(max_res_log2)  # reference image_generator.py:46-74
 
     def attach_decoder(self, dcfg, dparams):
-        """Put a decoder on the same GPU so ``generate_batch`` can run the fused path."""
-        dec = dparams if isinstance(dparams, Decoder) else None
-        if dec is None:
-            dec = Decoder(dcfg, 1, device=self.ctx[0], precision=self.precision)
+        """Load a decoder into the context of every generator replica so that ``generate_batch`` can run the fused
+        path (the features never leave the kernels' layout).  ``dparams``: a ``{name: array}`` dict, a ``.params``
+        path, or a loaded ``Decoder`` (e.g. ``SegSolver.net``) whose weights are copied -- that object stays
+        independent, as two gluon blocks would."""
+        if isinstance(dparams, Decoder):
+            if dparams._tensors is None:
+                raise RuntimeError("the decoder to attach has no parameters loaded")
+            dcfg, dparams = dparams.cfg, dparams._tensors
+        self._decoders = []
+        for g in self._gens:
+            if g._model.decoder_cfg is not None:        # re-attach: a fresh decoder slot in the same context
+                g._model.decoder_cfg = None
+            dec = Decoder(dcfg, len(self._gens), model=g._model)
             dec.load_parameters(dparams)
-        if dec._model is not self.netG._model:
-            raise RuntimeError("the decoder lives on another device or precision than the generator "
-                               "(%s vs %s)" % (dec.precision, self.precision))
-        self._decoder = dec
-        return dec
+            self._decoders.append(dec)
+        self._decoder = self._decoders[0]
+        return self._decoder
 
     @staticmethod
     def _transform_gan_back(img, cfg):
@@ -112,12 +130,24 @@ class ImageGenerator:
             nz = None
             if noise is not None:
                 nz = [a[n_generated:n_generated + bs] for a in noise]
-            _rgb, feats, imgs = self.netG(latent_z, noise=nz, want_image=True)
+            # data-parallel split over the device list, host-side gather (reference :95-114); the launches of all
+            # devices are enqueued before the first result is awaited
+            parts = []
+            for r, lo, hi in split_sizes(bs, len(self._gens)):
+                g = self._gens[r]
+                with torch.cuda.device(g._model.device):
+                    parts.append(g(latent_z[lo:hi], noise=None if nz is None else [a[lo:hi] for a in nz], want_image=True))
             latent_z_np = latent_z.numpy()
             if not keep_on_device:
-                torch.cuda.synchronize()
-                imgs = imgs.cpu().numpy()
-                feats = [f.cpu().numpy() for f in feats]
+                for g in self._gens:
+                    torch.cuda.synchronize(g._model.device)
+                imgs = np.concatenate([p[2].cpu().numpy() for p in parts], axis=0)
+                feats = [np.concatenate([p[1][i].cpu().numpy() for p in parts], axis=0) for i in range(len(parts[0][1]))]
+            else:
+                dev0 = self._gens[0]._model.device
+                imgs = torch.cat([p[2].to(dev0) for p in parts], dim=0) if len(parts) > 1 else parts[0][2]
+                feats = ([torch.cat([p[1][i].to(dev0) for p in parts], dim=0) for i in range(len(parts[0][1]))]
+                         if len(parts) > 1 else parts[0][1])
             n_generated += bs
             for i in range(bs):
                 img = imgs[i]
@@ -131,17 +161,28 @@ class ImageGenerator:
     def generate_indexed(self, first_index, n, seed=0, out=None):
         """``generate_batch`` for the global samples ``first_index .. first_index+n-1`` with counter-based latents
         and noise (``Generator.draw_indexed``): the dataset does not depend on how it is sharded."""
-        z, noise = self.netG.draw_indexed(first_index, n, seed)
-        return self.generate_batch(z, noise, out=out)
+        if len(self._gens) == 1:
+            z, noise = self.netG.draw_indexed(first_index, n, seed)
+            return self.generate_batch(z, noise, out=out)
+        parts = []
+        for r, lo, hi in split_sizes(n, len(self._gens)):
+            g = self._gens[r]
+            with torch.cuda.device(g._model.device):
+                z, noise = g.draw_indexed(first_index + lo, hi - lo, seed)
+                parts.append(self._generate_on(r, z, noise))
+        return self._collect(parts, n, out)
 
-    def generate_batch(self, z, noise=None, out=None):
-        """latents (N,512) [+ noise planes] -> (img (N,R,R,3) u8, mask (N,R,R) u8) on the GPU.
-        The per-batch body of ``main.py generate`` (reference main.py:97-99) in one call.
-        ``out=(img, mask)``: write into these contiguous uint8 device tensors instead of new ones
-        (e.g. the fused send buffer of ``dist.PairGatherer``)."""
-        if self._decoder is None:
-            raise RuntimeError("attach_decoder() first")
-        g = self.netG
+    def _check_out(self, out, n, dev):
+        R, nc = 2 ** self.max_res_log2, self.netG.nc
+        img, mask = out
+        for t, shape in ((img, (n, R, R, nc)), (mask, (n, R, R))):
+            if tuple(t.shape) != shape or t.dtype != torch.uint8 or t.device != dev or not t.is_contiguous():
+                raise ValueError("out tensors must be contiguous uint8 %s on %s" % (shape, dev))
+        return img, mask
+
+    def _generate_on(self, r, z, noise, out=None):
+        """The fused step on replica ``r`` (its own device and stream)."""
+        g = self._gens[r]
         z, noise, n = g._prepare(z, noise)
         model = g._model
         dev = model.device
@@ -150,10 +191,36 @@ class ImageGenerator:
             img = torch.empty((n, R, R, g.nc), device=dev, dtype=torch.uint8)
             mask = torch.empty((n, R, R), device=dev, dtype=torch.uint8)
         else:
-            img, mask = out
-            for t, shape in ((img, (n, R, R, g.nc)), (mask, (n, R, R))):
-                if tuple(t.shape) != shape or t.dtype != torch.uint8 or t.device != dev or not t.is_contiguous():
-                    raise ValueError("out tensors must be contiguous uint8 %s on %s" % (shape, dev))
+            img, mask = self._check_out(out, n, dev)
         model.ctx.generate(current_stream_ptr(dev), n, z.data_ptr(), [a.data_ptr() for a in noise],
                            img.data_ptr(), mask.data_ptr())
         return img, mask
+
+    def _collect(self, parts, n, out):
+        """Per-device results -> one (img, mask) pair on the first device, in sample order."""
+        dev0 = self._gens[0]._model.device
+        img = torch.cat([p[0].to(dev0, non_blocking=True) for p in parts], dim=0)
+        mask = torch.cat([p[1].to(dev0, non_blocking=True) for p in parts], dim=0)
+        if out is not None:
+            oi, om = self._check_out(out, n, dev0)
+            oi.copy_(img)
+            om.copy_(mask)
+            return oi, om
+        return img, mask
+
+    def generate_batch(self, z, noise=None, out=None):
+        """latents (N,512) [+ noise planes] -> (img (N,R,R,3) u8, mask (N,R,R) u8) on the GPU.
+        The per-batch body of ``main.py generate`` (reference main.py:97-99) in one call.
+        ``out=(img, mask)``: write into these contiguous uint8 device tensors instead of new ones
+        (e.g. the fused send buffer of ``dist.PairGatherer``).  With several gpu ids the batch is split over the
+        replicas like the reference's ``split_and_load`` and the pairs are collected on the first device."""
+        if self._decoder is None:
+            raise RuntimeError("attach_decoder() first")
+        if len(self._gens) == 1:
+            return self._generate_on(0, z, noise, out)
+        n = len(z)
+        parts = []
+        for r, lo, hi in split_sizes(n, len(self._gens)):
+            with torch.cuda.device(self._gens[r]._model.device):
+                parts.append(self._generate_on(r, z[lo:hi], None if noise is None else [a[lo:hi] for a in noise]))
+        return self._collect(parts, n, out)

@@ -21,6 +21,33 @@ def load_config_file(path):
         return yaml.safe_load(f)   # reference utils.py:112-115
 
 
+def devices_for_rank(cfg, world, local_rank):
+    """(GAN device list, solver device list) of this process.  One process (the reference's way, main.py:79-88):
+    the whole ``GAN_GPU_IDS`` / ``SOLVER_GPU_IDS`` lists, batch split over them in-process.  Under torchrun (one
+    process per GPU): rank r drives ``GAN_GPU_IDS[r % len]`` alone (an empty list = device ``local_rank``)."""
+    gan_ids = list(cfg.get("GAN_GPU_IDS") or [])
+    solver_ids = list(cfg.get("SOLVER_GPU_IDS") or gan_ids)
+    if world > 1:
+        gpu = gan_ids[local_rank % len(gan_ids)] if gan_ids else local_rank
+        return [gpu], [gpu]
+    if not gan_ids:
+        raise RuntimeError("GAN_GPU_IDS is empty: the MI355X path has no CPU context (reference image_generator.py:17)")
+    return gan_ids, solver_ids[:1] if solver_ids else gan_ids[:1]
+
+
+def shard_batches(n_generate, batch, world, rank):
+    """(first global sample index, samples) of every batch THIS rank produces: rank r owns the contiguous slice
+    ``dist.shard_bounds(n_generate, world, r)`` of the file indices and walks it in batches, the last one short
+    (reference main.py:93-99 with image_generator.py:88-92).  The slices of all ranks partition [0, n_generate)."""
+    from .dist import shard_bounds
+    lo, hi = shard_bounds(n_generate, world, rank)
+    index = lo
+    while index < hi:
+        bs = min(batch, hi - index)
+        yield index, bs
+        index += bs
+
+
 def generate(cfg, limit=None, workers=None):
     import torch
     from . import dist as gdist
@@ -29,39 +56,36 @@ def generate(cfg, limit=None, workers=None):
     from .seg_solver import SegSolver
     from .weights import GAN_MAX_RES_LOG2
 
-    rank, world, local_rank = gdist.init_from_env()
+    # ranks never exchange anything here (every rank writes its own files), so no process group is created:
+    # RANK / WORLD_SIZE / LOCAL_RANK alone decide the shard
+    rank, world, local_rank = gdist.env_ranks()
     root_dir, gan, gan_dir = cfg["BASE_DIR"], cfg["GAN"], cfg["GAN_DIR"]
-    gpu_ids = list(cfg["GAN_GPU_IDS"])
-    gpu = gpu_ids[local_rank % len(gpu_ids)] if world == 1 and gpu_ids else local_rank
+    gan_ids, solver_ids = devices_for_rank(cfg, world, local_rank)
     n_generate = cfg.get("GENERATE_NUM", 10000) if limit is None else limit
-    batch = cfg["GAN_BATCH_SIZE_PER_GPU"]
+    batch = cfg["GAN_BATCH_SIZE_PER_GPU"] * len(gan_ids)      # reference main.py:87
     seed = int(cfg.get("SEED", 0))             # additive key: seed of the counter-based latents/noise
     precision = cfg.get("PRECISION", "fp32")   # additive key: "bf16" = bf16 MFMA operands (BASELINE config 5)
 
     solver = SegSolver(GAN_MAX_RES_LOG2[gan], os.path.join(root_dir, "data"), os.path.join(root_dir, "checkpoints"),
-                       gpu_ids=[gpu], keep_weights=False, precision=precision)
+                       gpu_ids=solver_ids, keep_weights=False, precision=precision)
     if not solver.is_trained:
         print("train Decoder first!")   # reference main.py:82-84
         return -1
-    netG = ImageGenerator(gpu_ids=[gpu], gan_dir=gan_dir, gan=gan, batch_size=batch, precision=precision)
+    netG = ImageGenerator(gpu_ids=gan_ids, gan_dir=gan_dir, gan=gan, batch_size=batch, precision=precision)
     netG.attach_decoder(solver.cfg, solver.net)
     dst_dir = os.path.join(root_dir, "dataset", "train_generated")
     os.makedirs(dst_dir, exist_ok=True)
 
-    lo, hi = gdist.shard_bounds(n_generate, world, rank)
-    index = lo
     # the writer copies each batch out through pinned buffers and encodes it on a thread pool while the
     # GPU already computes the next one
     # additive keys JPEG_ON_GPU / PNG_ON_GPU (default on): the files are compressed by the HIP kernels behind
     # include/gsa_jpeg.h and include/gsa_png.h; the host threads only frame and write them
     on_gpu = bool(cfg.get("JPEG_ON_GPU", True))
     with DatasetWriter(dst_dir, workers=workers, gpu_jpeg=on_gpu, gpu_png=bool(cfg.get("PNG_ON_GPU", on_gpu))) as writer:
-        while index < hi:
-            bs = min(batch, hi - index)
+        for index, bs in shard_batches(n_generate, batch, world, rank):
             # latents and noise keyed on the global sample index: the files are the same for any number of ranks
             img, mask = netG.generate_indexed(index, bs, seed=seed)
             writer.submit(img, mask, index)
-            index += bs
     torch.cuda.synchronize()
     return 0
 

@@ -13,18 +13,23 @@ from ._runtime import DeviceModel, current_stream_ptr, to_device_f32
 
 
 class Decoder:
-    def __init__(self, cfg, num_devices=1, device=0, precision="fp32", **kwargs):
+    def __init__(self, cfg, num_devices=1, device=0, precision="fp32", model=None, **kwargs):
         self.cfg = dict(cfg)
         for key in ("features", "in_channels", "start_res", "use_bn", "use_sync_bn", "use_dropout"):
             if key not in self.cfg:
                 raise KeyError("Decoder cfg is missing %r" % key)  # reference :54-62
         self._num_devices = num_devices
         self.precision = precision
-        self._model = DeviceModel.get(device, precision)
+        # its own context unless it is to run fused with a generator (``model`` = that generator's context)
+        self._model = model if model is not None else DeviceModel(device, precision)
+        if self._model.decoder_cfg is not None:
+            raise RuntimeError("this context already holds a Decoder")
+        self.precision = self._model.precision
         self._model.ctx.decoder_init(self.cfg)
         self._model.decoder_cfg = self.cfg
         self._model.invalidate_workspace()
         self._loaded = False
+        self._tensors = None
 
     def hybridize(self, *args, **kwargs):  # reference seg_solver.py:41 -- nothing to trace here
         return None

@@ -22,7 +22,7 @@ from ._runtime import DeviceModel, current_stream_ptr, to_device_f32
 
 
 class Generator:
-    def __init__(self, config, device=0, precision="fp32", **kwargs):
+    def __init__(self, config, device=0, precision="fp32", model=None, **kwargs):
         self.config = dict(config)
         for key in ("fmap_base", "fmap_decay", "fmap_max", "base_scale_x", "base_scale_y", "use_wscale",
                     "fix_noise", "channels", "latent_size", "max_res_log2"):
@@ -33,7 +33,10 @@ class Generator:
         self.latent_size = self.config["latent_size"]
         self.max_res_log2 = self.config["max_res_log2"]
         self.precision = precision
-        self._model = DeviceModel.get(device, precision)
+        # its own context: a second Generator on the same GPU must not touch this one's weights or configuration
+        self._model = model if model is not None else DeviceModel(device, precision)
+        if self._model.generator_cfg is not None:
+            raise RuntimeError("this context already holds a Generator")
         self._model.ctx.generator_init(self.config)
         self._model.generator_cfg = self.config
         self._model.invalidate_workspace()

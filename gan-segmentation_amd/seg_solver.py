@@ -25,23 +25,23 @@ class SegSolver:
         if len(gpu_ids) == 0:
             raise RuntimeError("the MI355X path has no CPU context: pass a gpu id "
                                "(the reference falls back to mx.cpu(), seg_solver.py:24-26)")
-        if len(gpu_ids) > 1:
-            raise RuntimeError("one process drives one GPU; shard across ranks with gan_segmentation_amd.dist")
-        self.ctx = gpu_ids
+        self.ctx = gpu_ids      # the reference's device list (seg_solver.py:24-28): one decoder replica per entry
         self.precision = precision
         self.is_trained = False
         self.params_file = None
         self.cfg = self.get_config(max_res_log2=max_res_log2, in_channels=in_channels)
-        self.net = self.init_net()
+        self.nets = [self.init_net(dev) for dev in self.ctx]
+        self.net = self.nets[0]
         self.is_trained = self.load()
 
     def get_config(self, max_res_log2=9, in_channels=None):
         return _weights.decoder_config(max_res_log2, in_channels=in_channels)  # reference :83-132
 
-    def init_net(self):
+    def init_net(self, device=None):
         # the reference also Xavier-initialises here (:38-46); without a checkpoint this solver
         # is simply "not trained" and predict() refuses to run
-        return Decoder(self.cfg, num_devices=len(self.ctx), device=self.ctx[0], precision=self.precision)
+        return Decoder(self.cfg, num_devices=len(self.ctx), device=self.ctx[0] if device is None else device,
+                       precision=self.precision)
 
     def load(self):
         """Load the first ``*.params`` file of the checkpoints dir (reference :339-349)."""
@@ -51,11 +51,14 @@ class SegSolver:
         if not files:
             return False
         self.params_file = files[0]
-        self.net.load_parameters(os.path.join(self.checkpoints_dir, files[0]))
+        self.load_parameters(os.path.join(self.checkpoints_dir, files[0]))
         return True
 
     def load_parameters(self, source):
-        self.net.load_parameters(source)
+        from . import params as _params
+        tensors = _params.load_params(source) if isinstance(source, (str, bytes)) else dict(source)
+        for net in self.nets:       # full replica per device (reference: load_parameters(..., ctx=self.ctx))
+            net.load_parameters(tensors)
         self.is_trained = True
 
     def save(self, suffix=None):
@@ -69,11 +72,24 @@ class SegSolver:
         (argmax over classes, first maximum; reference :307-329)."""
         if not self.is_trained:
             raise RuntimeError("train Decoder first! (no checkpoint loaded)")
-        _logits, mask = self.net(*features, want_mask=True)
+        n = 1 if np.ndim(features[0]) == 3 else len(features[0])
+        if len(self.nets) == 1 or n == 1:
+            _logits, mask = self.net(*features, want_mask=True)
+        else:
+            # split over the device list, gather on the first device (reference :317-325)
+            from ._runtime import split_sizes
+            parts = []
+            for r, lo, hi in split_sizes(n, len(self.nets)):
+                net = self.nets[r]
+                with torch.cuda.device(net._model.device):
+                    parts.append(net(*[f[lo:hi] for f in features], want_mask=True)[1])
+            dev0 = self.net._model.device
+            mask = torch.cat([m.to(dev0) for m in parts], dim=0)
         mask = mask.unsqueeze(-1)
         if keep_on_device:
             return mask.to(torch.float32)
-        torch.cuda.synchronize()
+        for net in self.nets:
+            torch.cuda.synchronize(net._model.device)
         return mask.cpu().numpy().astype(np.float32)
 
     # -- training (SURVEY.md section 8f-3) ---------------------------------------------------------
@@ -98,9 +114,14 @@ class SegSolver:
         epochs = 24 if epochs is None else epochs                                                # reference cfg['train_epochs']
         rng = random.Random(seed)
         history = []
+        import torch.distributed as tdist
+        world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
+        rank = tdist.get_rank() if world > 1 else 0
         for epoch in range(epochs):
             order = list(names)
-            rng.shuffle(order)
+            rng.shuffle(order)           # the same permutation on every rank (same seed) ...
+            if world > 1 and len(order) >= world:   # ... of which rank r takes every world-th sample: the trainer
+                order = order[:len(order) - len(order) % world][rank::world]   # all-reduces the gradients, so a step sees `world` samples
             total = 0.0
             for fname in order:
                 image_id = int(os.path.splitext(fname)[0].split("_")[-1])
@@ -113,9 +134,9 @@ class SegSolver:
                 log("Epoch[%d] Train-total-loss=%f" % (epoch + 1, history[-1]))
             if epoch_end_callback is not None:
                 epoch_end_callback()
-        self.net.load_parameters(tr.state_dict())
-        self.is_trained = True
-        self.save()
+        self.load_parameters(tr.state_dict())
+        if rank == 0:
+            self.save()
         return history
 
     # -- evaluation ------------------------------------------------------

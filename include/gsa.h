@@ -103,24 +103,28 @@ int gsa_reserve(gsa_ctx* ctx, int32_t max_batch);
  *   rgb    dev (N,channels,R,R) fp32 or NULL     -- first return value of the reference
  *   img    dev (N,R,R,channels) u8 or NULL       -- _transform_gan_back of rgb
  *   feats  NULL or host array of max_res_log2-1 dev pointers, each (N,C_r,R_r,R_r) fp32 or
- *          NULL                                   -- second return value of the reference */
+ *          NULL                                   -- second return value of the reference
+ *   num_noise / num_feats  entries in the two pointer arrays: must equal 2*(max_res_log2-1) and (when feats is
+ *          given) max_res_log2-1 of THIS context's generator -- a caller holding arrays sized for another
+ *          configuration gets GSA_ERR_INVALID instead of an out-of-bounds read */
 int gsa_generator_forward(gsa_ctx* ctx, void* stream, int32_t n, const float* z,
-                          const float* const* noise, float* rgb, uint8_t* img,
-                          float* const* feats);
+                          const float* const* noise, int32_t num_noise, float* rgb, uint8_t* img,
+                          float* const* feats, int32_t num_feats);
 
 /* Decoder.hybrid_forward + argmax of SegSolver.predict (reference networks_seg.py:97-113,
  * seg_solver.py:321-327).
  *   feats  host array of num_feats dev pointers, each (N,in_channels[i],R_i,R_i) fp32
  *   logits dev (N,num_classes,R,R) fp32 or NULL
+ *   num_feats  entries in feats; must equal the decoder's num_feats (GSA_ERR_INVALID otherwise)
  *   mask   dev (N,R,R) u8 class index (first maximum wins) or NULL */
 int gsa_decoder_forward(gsa_ctx* ctx, void* stream, int32_t n, const float* const* feats,
-                        float* logits, uint8_t* mask);
+                        int32_t num_feats, float* logits, uint8_t* mask);
 
 /* The fused `main.py generate` step (reference main.py:97-99): generator and decoder with
  * the feature maps kept in HBM in the kernels' own layout.  Bitwise identical to
  * gsa_generator_forward + gsa_decoder_forward on the same inputs. */
 int gsa_generate(gsa_ctx* ctx, void* stream, int32_t n, const float* z,
-                 const float* const* noise, uint8_t* img, uint8_t* mask);
+                 const float* const* noise, int32_t num_noise, uint8_t* img, uint8_t* mask);
 
 /* gsa_generate runs the decoder on a second HIP stream beside the synthesis of the higher
  * resolutions (fork/join through events).  `levels` = number of decoder levels placed there; negative = the default:
@@ -145,9 +149,9 @@ int gsa_set_precision(gsa_ctx* ctx, int32_t mode);
  * sample's inputs do not depend on the batch, rank or GPU count that produces it.
  * Replaces mx.nd.random.randn (reference image_generator.py:94) and AddNoise's random_normal
  * (networks_stylegan.py:297-300) when the caller wants reproducible shards; latent_size % 4 == 0.
- * Either pointer may be NULL. */
+ * Either pointer may be NULL; num_noise = entries in noise (must be 2*(max_res_log2-1) when noise is given). */
 int gsa_fill_inputs(gsa_ctx* ctx, void* stream, int32_t n, uint64_t seed, uint64_t first_index, float* z,
-                    float* const* noise);
+                    float* const* noise, int32_t num_noise);
 
 /* Per-batch arithmetic of SegSolver.evaluate_for_data (reference seg_solver.py:229-262) and
  * SegmentationMetric.update (reference metrics.py:497-606), SURVEY.md section 8f-4:

@@ -640,10 +640,12 @@ static void nchw_to_nhwc(const float* in, int H, int W, int C, float* out) {
 GSAO_API int gsao_reserve(gsao_ctx* c, int32_t max_batch) { (void)c; (void)max_batch; return GSA_OK; }
 
 GSAO_API int gsao_generator_forward(gsao_ctx* c, void* stream, int32_t n, const float* z, const float* const* noise,
-                                    float* rgb, uint8_t* img, float* const* feats) {
+                                    int32_t num_noise, float* rgb, uint8_t* img, float* const* feats, int32_t num_feats) {
     (void)stream;
     if (!c || !c->g_ready) return fail(c, GSA_ERR_STATE, "generator_commit first%s (%ld)", "", 0);
     if (n < 0 || !z || !noise) return fail(c, GSA_ERR_INVALID, "bad arguments to generator_forward%s (%ld)", "", n);
+    if (num_noise != 2 * c->nlev || (feats && num_feats != c->nlev))
+        return fail(c, GSA_ERR_INVALID, "noise / feature pointer counts do not match this generator%s (%ld)", "", num_noise);
     const int L = c->gc.latent_size, nlev = c->nlev, nc = c->gc.channels;
     const int Cmax = c->ch[0] > 0 ? 512 : 0;
     (void)Cmax;
@@ -834,10 +836,12 @@ static void bias_bn_act(float* x, size_t npix, int C, const float* bias, const f
         }
 }
 
-GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const float* const* feats, float* logits, uint8_t* mask) {
+GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const float* const* feats, int32_t num_feats, float* logits,
+                                  uint8_t* mask) {
     (void)stream;
     if (!c || !c->d_ready) return fail(c, GSA_ERR_STATE, "decoder_commit first%s (%ld)", "", 0);
     if (n < 0 || !feats) return fail(c, GSA_ERR_INVALID, "bad arguments to decoder_forward%s (%ld)", "", n);
+    if (num_feats != c->d_n) return fail(c, GSA_ERR_INVALID, "feature pointer count does not match this decoder%s (%ld)", "", num_feats);
     const int nl = c->d_n;
     /* feature i is at 4*2^i pixels (the generator's 4..2^max ladder, reference networks_stylegan.py:184-192) */
     size_t maxbuf = 0;
@@ -921,9 +925,11 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
     return GSA_OK;
 }
 
-GSAO_API int gsao_generate(gsao_ctx* c, void* stream, int32_t n, const float* z, const float* const* noise, uint8_t* img, uint8_t* mask) {
+GSAO_API int gsao_generate(gsao_ctx* c, void* stream, int32_t n, const float* z, const float* const* noise, int32_t num_noise,
+                           uint8_t* img, uint8_t* mask) {
     if (!c || !c->g_ready || !c->d_ready) return fail(c, GSA_ERR_STATE, "commit generator and decoder first%s (%ld)", "", 0);
     const int nlev = c->nlev;
+    if (num_noise != 2 * nlev) return fail(c, GSA_ERR_INVALID, "noise plane count does not match this generator%s (%ld)", "", num_noise);
     if (c->d_n != nlev) return fail(c, GSA_ERR_INVALID, "decoder expects %s%ld features, generator yields a different count", "", c->d_n);
     float* feats[MAX_LEVELS];
     const float* cf[MAX_LEVELS];
@@ -939,9 +945,9 @@ GSAO_API int gsao_generate(gsao_ctx* c, void* stream, int32_t n, const float* z,
             nz[2 * l + 1] = noise[2 * l + 1] + (size_t)s * npix;
         }
         const size_t R = (size_t)1 << c->gc.max_res_log2;
-        rc = gsao_generator_forward(c, stream, 1, z + (size_t)s * c->gc.latent_size, nz, NULL,
-                                    img ? img + (size_t)s * R * R * c->gc.channels : NULL, feats);
-        if (rc == GSA_OK) rc = gsao_decoder_forward(c, stream, 1, cf, NULL, mask ? mask + (size_t)s * R * R : NULL);
+        rc = gsao_generator_forward(c, stream, 1, z + (size_t)s * c->gc.latent_size, nz, 2 * nlev, NULL,
+                                    img ? img + (size_t)s * R * R * c->gc.channels : NULL, feats, nlev);
+        if (rc == GSA_OK) rc = gsao_decoder_forward(c, stream, 1, cf, nlev, NULL, mask ? mask + (size_t)s * R * R : NULL);
         for (int l = 0; l < nlev; ++l) free(feats[l]);
     }
     return rc;

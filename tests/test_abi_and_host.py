@@ -245,3 +245,109 @@ def test_bench_reads_every_committed_pmc_summary():
         hit = bench.pmc_traffic(kernels[0]["kernel"])
         assert hit is not None and hit["bytes_per_launch"] > 0
     assert bench.pmc_traffic("no such kernel") is None
+
+
+_WORKER4 = r'''
+import os, sys
+sys.path.insert(0, ROOT_DIR)
+import numpy as np, torch
+import torch.distributed as dist
+from gan_segmentation_amd import dist as gdist
+from gan_segmentation_amd import main as cli
+rank, world, _ = gdist.init_from_env(backend="gloo")
+assert world == 4
+R, ch, B = 8, 3, 3
+
+def pair(index):        # a recognisable (image, mask) per GLOBAL sample index -- stands in for the HIP producer
+    g = np.random.default_rng(index)
+    return g.integers(0, 256, (R, R, ch), dtype=np.uint8), g.integers(0, 2, (R, R), dtype=np.uint8)
+
+# ---- (1) PairGatherer, depth 2, five batches: every slot is reused (wrap-around) while the previous gather of
+# that slot is awaited only when the slot comes round again, as bench.py does
+gat = gdist.PairGatherer(B, R, ch, device="cpu", dst=0, depth=2)
+for k in range(5):
+    slot = k % 2
+    gat.wait(slot)
+    if rank == 0 and k >= 2:      # what the slot held from batch k-2 must have been complete before it is overwritten
+        parts = gat.result(slot)
+        for r in range(world):
+            for j in range(B):
+                wi, wm = pair(((k - 2) * world + r) * B + j)
+                assert np.array_equal(parts[r][0][j].numpy(), wi) and np.array_equal(parts[r][1][j].numpy(), wm), (k, r, j)
+    iv, mv = gat.buffers(slot)
+    for j in range(B):
+        wi, wm = pair((k * world + rank) * B + j)
+        iv[j].copy_(torch.from_numpy(wi)); mv[j].copy_(torch.from_numpy(wm))
+    gat.submit(slot)
+gat.wait_all()
+if rank == 0:
+    for k in (3, 4):
+        parts = gat.result(k % 2)
+        for r in range(world):
+            for j in range(B):
+                wi, wm = pair((k * world + r) * B + j)
+                assert np.array_equal(parts[r][0][j].numpy(), wi) and np.array_equal(parts[r][1][j].numpy(), wm)
+    print("GATHERER4_OK")
+
+# ---- (2) ragged last batch through the blocking form: 10 samples over 4 ranks = 3, 3, 2, 2
+total = 10
+lo, hi = gdist.shard_bounds(total, world, rank)
+counts = [gdist.shard_bounds(total, world, r)[1] - gdist.shard_bounds(total, world, r)[0] for r in range(world)]
+assert counts == [3, 3, 2, 2]
+mine = [pair(1000 + i) for i in range(lo, hi)]
+gi, gm = gdist.gather_pairs(torch.from_numpy(np.stack([p[0] for p in mine])), torch.from_numpy(np.stack([p[1] for p in mine])), counts=counts)
+if rank == 0:
+    assert gi.shape[0] == total
+    for i in range(total):
+        wi, wm = pair(1000 + i)
+        assert np.array_equal(gi[i].numpy(), wi) and np.array_equal(gm[i].numpy(), wm)
+    print("RAGGED4_OK")
+else:
+    assert gi is None and gm is None
+
+# ---- (3) `main.py generate` under torchrun: the file indices of the ranks partition [0, GENERATE_NUM)
+for n_generate, batch in ((10, 4), (3, 8), (10000, 32), (17, 1)):
+    mine = [i for first, bs in cli.shard_batches(n_generate, batch, world, rank) for i in range(first, first + bs)]
+    sizes = [bs for _f, bs in cli.shard_batches(n_generate, batch, world, rank)]
+    assert all(0 < b <= batch for b in sizes) and all(b == batch for b in sizes[:-1])
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    if rank == 0:
+        flat = [i for part in every for i in part]
+        assert flat == list(range(n_generate)), (n_generate, batch)          # disjoint, complete, in rank order
+r2, w2, l2 = gdist.env_ranks()
+assert (r2, w2) == (rank, world)
+assert cli.devices_for_rank({"GAN_GPU_IDS": [4, 5]}, world, l2) == ([[4, 5][l2 % 2]],) * 2
+assert cli.devices_for_rank({"GAN_GPU_IDS": []}, world, l2) == ([l2], [l2])
+if rank == 0:
+    print("SHARDS4_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_world_size_4_gatherer_and_generate_shards_on_gloo(tmp_path):
+    """Multi-GPU readiness without hardware: four ranks over gloo -- the overlapped gatherer with slot wrap-around, the
+    ragged blocking gather, and the shard arithmetic of `main.py generate` (reference image_generator.py:95:
+    split_and_load(even_split=False); main.py:93-103)."""
+    script = tmp_path / "worker4.py"
+    script.write_text(_WORKER4.replace("ROOT_DIR", repr(ROOT)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+         "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+        capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    for tag in ("GATHERER4_OK", "RAGGED4_OK", "SHARDS4_OK"):
+        assert tag in out.stdout, out.stdout[-2000:]
+
+
+def test_generate_devices_single_process():
+    """One process (the reference's way): the whole GAN_GPU_IDS list is used in-process, the batch is
+    GAN_BATCH_SIZE_PER_GPU * len(GAN_GPU_IDS) (reference main.py:87-88); an empty list has no CPU fallback."""
+    from gan_segmentation_amd import main as cli
+    assert cli.devices_for_rank({"GAN_GPU_IDS": [0, 1, 2], "SOLVER_GPU_IDS": [1]}, 1, 0) == ([0, 1, 2], [1])
+    assert cli.devices_for_rank({"GAN_GPU_IDS": [3]}, 1, 0) == ([3], [3])
+    with pytest.raises(RuntimeError):
+        cli.devices_for_rank({"GAN_GPU_IDS": []}, 1, 0)
+    assert [b for b in cli.shard_batches(5, 2, 1, 0)] == [(0, 2), (2, 2), (4, 1)]

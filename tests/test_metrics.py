@@ -59,7 +59,7 @@ def test_device_eval_kernel(k):
     rng = np.random.default_rng(10 + k)
     logits, labels = _random_case(rng, 3, k, 64)
     logits[0, :, 0, 0] = 1.5                                  # a tie: first maximum wins
-    model = DeviceModel.get(0)
+    model = DeviceModel(0)
     dev = model.device
     lg = torch.from_numpy(logits).to(dev)
     lb = torch.from_numpy(labels.astype(np.int8)).to(dev)

@@ -20,7 +20,6 @@ gcfg, dcfg = W.generator_config(mr), W.decoder_config(mr)
 gp, dp = W.synthetic_generator_params(gcfg, seed=2), W.synthetic_decoder_params(dcfg, seed=3)
 gens = []
 for _ in range(2):
-    _runtime.DeviceModel._by_device.clear()          # a second, independent context (weights + workspace)
     gens.append(ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[0], batch_size=B))
 z, noise = W.synthetic_inputs(gcfg, B)
 z = torch.from_numpy(z).cuda()
