@@ -41,6 +41,7 @@ struct GenBlockDev {
     float* nscale[2] = {nullptr, nullptr};
     float* nbias[2] = {nullptr, nullptr};
     float* w2 = nullptr;
+    float* w2u = nullptr; // conv_2 in Winograd form (layers the static rule selects), or null
     float* gamma[2] = {nullptr, nullptr};
     float* beta[2] = {nullptr, nullptr};
     int style_off[2] = {0, 0};  // column offset of this layer's 2C styles
@@ -50,6 +51,7 @@ struct DecLevelDev {
     int F = 0, I = 0, in_c = 0, cs = 0;
     bool is_last = false, has_sc = false;
     float *cvt_w = nullptr, *cvt_b = nullptr, *cvt_s = nullptr, *cvt_rm = nullptr, *cvt_beta = nullptr;
+    float *cvt_u = nullptr, *b_u = nullptr;   // Winograd forms of cvt / conv b, or null
     float *a_w = nullptr, *a_b = nullptr, *a_s = nullptr, *a_rm = nullptr, *a_beta = nullptr;
     float *b_w = nullptr, *b_b = nullptr, *b_s = nullptr, *b_rm = nullptr, *b_beta = nullptr;
     float *sc_w = nullptr, *sc_b = nullptr;
@@ -117,6 +119,7 @@ struct gsa_ctx {
     hipEvent_t ev_level[kMaxLevels] = {nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int bf16 = 0;                 // gsa_set_precision: 1 = bf16 MFMA operands (fixed once weights are committed)
+    int prio = 0;                 // GSA_PRIO experiment switch
     int dbg = 0;                  // GSA_DBG, read once at gsa_create (only the diagnostic build looks at it)
     int side_levels = -1;         // decoder levels 0..side_levels-1 go to the side stream; -1 = by batch size (GSA_SIDE_LEVELS)
 
@@ -285,6 +288,43 @@ std::vector<float> pack_conv1(const float* w, int O, int I) {
                             w[(size_t)(g * ct + n) * I + cb * 16 + cg * 4 + ci];
     return out;
 }
+
+// Winograd F(2x2,3x3) weights of a 3x3 conv OIHW (O,I,3,3): U = G g G^T evaluated in double on the effective fp32
+// weights and rounded once (canonical arithmetic; the oracle's pack_wino is the same code path restated),
+// packed like a 16-tap kernel: [O/16][I/16][f = 4i+j][ci][16][cg]
+std::vector<float> pack_wino(const float* w, int O, int I, float std, bool us, float lr) {
+    std::vector<float> out((size_t)O * I * 16);
+    const int nblk = I / 16, G = O / 16;
+    for (int g = 0; g < G; ++g)
+        for (int cb = 0; cb < nblk; ++cb)
+            for (int ci = 0; ci < 4; ++ci)
+                for (int n = 0; n < 16; ++n)
+                    for (int cg = 0; cg < 4; ++cg) {
+                        const int o = g * 16 + n, ch = cb * 16 + cg * 4 + ci;
+                        const float* wk = w + ((size_t)o * I + ch) * 9;
+                        double k[3][3], r[4][3], u[4][4];
+                        for (int a = 0; a < 3; ++a)
+                            for (int b = 0; b < 3; ++b) k[a][b] = (double)eff(wk[a * 3 + b], std, us, lr);
+                        for (int b = 0; b < 3; ++b) {
+                            r[0][b] = k[0][b];
+                            r[1][b] = 0.5 * ((k[0][b] + k[1][b]) + k[2][b]);
+                            r[2][b] = 0.5 * ((k[0][b] - k[1][b]) + k[2][b]);
+                            r[3][b] = k[2][b];
+                        }
+                        for (int a = 0; a < 4; ++a) {
+                            u[a][0] = r[a][0];
+                            u[a][1] = 0.5 * ((r[a][0] + r[a][1]) + r[a][2]);
+                            u[a][2] = 0.5 * ((r[a][0] - r[a][1]) + r[a][2]);
+                            u[a][3] = r[a][2];
+                        }
+                        for (int f = 0; f < 16; ++f)
+                            out[((((((size_t)g * nblk + cb) * 16 + f) * 4 + ci) * 16 + n) * 4) + cg] = (float)u[f >> 2][f & 3];
+                    }
+    return out;
+}
+
+// the static rule of the Winograd form (gsa_kernels.hip conv_uses_wino): plain 3x3 convs with outputs >= 32 px, fp32 mode
+inline bool wino_layer(const gsa_ctx* c, int R) { return !c->bf16 && R >= 32; }
 
 // final conv (K,I,3,3) -> [cb][tap][c16][K]
 std::vector<float> pack_final(const float* w, int K, int I) {
@@ -462,6 +502,7 @@ int gsa_create(int device, gsa_ctx** out) {
     }
     if (const char* v = getenv("GSA_SIDE_LEVELS")) c->side_levels = atoi(v);
     if (const char* v = getenv("GSA_DBG")) c->dbg = atoi(v);
+    if (const char* v = getenv("GSA_PRIO")) c->prio = atoi(v);
     *out = c;
     return GSA_OK;
 }
@@ -587,6 +628,11 @@ int gsa_generator_commit(gsa_ctx* c) {
         NEED(P, std::string(nm) + "_weight", (size_t)C * C * 9, &w);
         h = pack_conv3(w, C, C, std, us, 1.0f);
         if (int rc = upload_mfma(c, h, &B.w2, T)) return rc;
+        B.w2u = nullptr;
+        if (wino_layer(c, R)) {
+            h = pack_wino(w, C, C, std, us, 1.0f);
+            if (int rc = upload(c, h, &B.w2u, T)) return rc;
+        }
         for (int k = 0; k < 2; ++k) {
             snprintf(nm, sizeof nm, "%d_noise_%d_scale_factors", R, k + 1);
             NEED(P, nm, (size_t)C, &w); h.assign(w, w + C);
@@ -711,6 +757,11 @@ int gsa_decoder_commit(gsa_ctx* c) {
         NEED(P, std::string(nm) + ".bias", (size_t)d.F, &b);
         h = pack_conv3(w, d.F, d.I, 1.0f, false, 1.0f);
         if (int rc = upload_mfma(c, h, &d.cvt_w, T)) return rc;
+        d.cvt_u = d.b_u = nullptr;
+        if (wino_layer(c, 4 << i)) {
+            h = pack_wino(w, d.F, d.I, 1.0f, false, 1.0f);
+            if (int rc = upload(c, h, &d.cvt_u, T)) return rc;
+        }
         h.assign(b, b + d.F);
         if (int rc = upload(c, h, &d.cvt_b, T)) return rc;
         snprintf(nm, sizeof nm, "cvt_block_%d.1", i);
@@ -729,6 +780,10 @@ int gsa_decoder_commit(gsa_ctx* c) {
             NEED(P, pf + "." + std::to_string(second) + ".bias", (size_t)d.cs, &b);
             h = pack_conv3(w, d.cs, d.cs, 1.0f, false, 1.0f);
             if (int rc = upload_mfma(c, h, &d.b_w, T)) return rc;
+            if (wino_layer(c, 8 << i)) {
+                h = pack_wino(w, d.cs, d.cs, 1.0f, false, 1.0f);
+                if (int rc = upload(c, h, &d.b_u, T)) return rc;
+            }
             h.assign(b, b + d.cs);
             if (int rc = upload(c, h, &d.b_b, T)) return rc;
             if (int rc = load_bn(c, pf + "." + std::to_string(second + 1), d.cs, &d.b_s, &d.b_rm, &d.b_beta)) return rc;
@@ -852,7 +907,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 if (!B.has_conv1) {
                     pp.src = c->constant; pp.src_per_sample = 0; pp.blur = nullptr;
                 } else {
-                    ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device;
+                    ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
                     cp.src0 = c->x2[l - 1]; cp.aff0 = c->aff2[l - 1]; cp.C0 = Cin;
                     cp.Hs = R / 2; cp.Ws = R / 2; cp.H = R; cp.W = R;
                     cp.wpk = B.w1; cp.Cout = C; cp.out = c->t_raw;
@@ -876,18 +931,17 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 HIP_TRY(launch_post(pp, n, s));
                 prow = post_prow(R, R, C);
             } else {
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
                 cp.src0 = c->x1; cp.aff0 = c->aff1; cp.C0 = C;
                 cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
-                cp.wpk = B.w2; cp.Cout = C; cp.out = c->x2[l];
-                cp.noise = nz; cp.nscale = B.nscale[1]; cp.nbias = B.nbias[1]; cp.partials = c->partials; cp.acc = c->stat_acc;
+                cp.wpk = B.w2; cp.wino = B.w2u; cp.Cout = C; cp.out = c->x2[l];
+                cp.noise = nz; cp.nscale = B.nscale[1]; cp.nbias = B.nbias[1]; cp.partials = c->partials;
                 snprintf(layer, sizeof layer, "g.%d.conv_2", R);
-                const bool ws = conv_uses_ws(cp, EPI_SYNTH, false, n);
                 int rows = conv_stat_rows(R, R, C, n);
-                cp.stat_rows_host = &rows;            // the launcher may sum straight into stat_acc (rows = 0)
-                Launch lp(c, s, ws ? "void gsa::conv3x3_ws<ws, 1>(gsa::ConvParams)" : conv_kernel_name(cp, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * 9, 4.0 * (2 * px * C + px));
+                cp.stat_rows_host = &rows;            // the launcher reports the partial rows it used
+                Launch lp(c, s, conv_kernel_name(cp, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * (conv_uses_wino(cp, EPI_SYNTH, false) ? 4 : 9), 4.0 * (2 * px * C + px));
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
-                prow = ws ? 0 : rows;
+                prow = rows;
             }
             FinalizeParams fp{};
             fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C; fp.acc = c->stat_acc; fp.tickets = c->stat_tickets;
@@ -927,20 +981,20 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
         const double px = N * R * R;
         if (wait_levels) HIP_TRY(hipStreamWaitEvent(s, c->ev_level[i], 0));   // generator feature i is ready
         {   // cvt_block: conv3x3+bias -> BN -> LeakyReLU (Dropout is identity at inference)
-            ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device;
+            ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
             cp.src0 = fsrc[i]; cp.aff0 = faff ? faff[i] : nullptr; cp.C0 = d.I;
             cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
-            cp.wpk = d.cvt_w; cp.Cout = d.F; cp.out = c->cvt[i];
+            cp.wpk = d.cvt_w; cp.wino = d.cvt_u; cp.Cout = d.F; cp.out = c->cvt[i];
             cp.bias = d.cvt_b; cp.bn_s = d.cvt_s; cp.bn_rm = d.cvt_rm; cp.bn_beta = d.cvt_beta;
             snprintf(layer, sizeof layer, "d.cvt_%d", i);
-            Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * 9, 4.0 * px * (d.I + d.F));
+            Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * (conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px * (d.I + d.F));
             HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
         }
         if (!d.is_last) {
             const int R2 = 2 * R;
             const double px2 = 4 * px;
             {   // ResBlock conv a (+ fused 1x1 shortcut) on nearest-x2(concat(prev, cvt))
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
                 if (i > s0) { cp.src0 = c->prev[i - 1]; cp.C0 = d.F; cp.src1 = c->cvt[i]; cp.C1 = d.F; }
                 else { cp.src0 = c->cvt[i]; cp.C0 = d.F; }
                 cp.Hs = R; cp.Ws = R; cp.up = 1; cp.H = R2; cp.W = R2;
@@ -962,16 +1016,16 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 }
             }
             {   // ResBlock conv b, + shortcut
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
                 cp.src0 = c->ya[i]; cp.C0 = d.cs;
                 cp.Hs = R2; cp.Ws = R2; cp.H = R2; cp.W = R2;
-                cp.wpk = d.b_w; cp.Cout = d.cs; cp.out = c->prev[i];
+                cp.wpk = d.b_w; cp.wino = d.b_u; cp.Cout = d.cs; cp.out = c->prev[i];
                 cp.bias = d.b_b; cp.bn_s = d.b_s; cp.bn_rm = d.b_rm; cp.bn_beta = d.b_beta;
                 if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = R2 >= 16 ? 1 : 0; }   // sub-pixel conv a stores the shortcut at input resolution
                 else if (i == s0) { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 else { cp.resid = c->prev[i - 1]; cp.resid1 = c->cvt[i]; cp.res_c0 = d.F; cp.resid_up = 1; }   // ... over concat(prev, cvt)
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
-                Launch lp(c, s, conv_uses_ws(cp, EPI_DEC, false, n) ? "void gsa::conv3x3_ws<ws, 2>(gsa::ConvParams)" : conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * 9, 4.0 * px2 * d.cs * 3);
+                Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * (conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px2 * d.cs * 3);
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
             }
         } else {

@@ -27,12 +27,12 @@ struct ConvParams {
     int up;          // 1: logical input is the nearest x2 upsample of the sources
     int H, W;        // output size
     const float* wpk;   // packed weights [Cout/16][Cin/16][tap][ci][16][cg]
+    const float* wino;  // or null: the same conv in Winograd F(2x2,3x3) form, U packed [Cout/16][Cin/16][f16][ci][16][cg]
     int Cout;           // total output channels
     float* out;         // NHWC
     // EPI_SYNTH: AddNoise -> Bias -> LeakyReLU -> statistics
     const float* noise; const float* nscale; const float* nbias;
     StatPart* partials; int prow;      // prow = partial rows per sample
-    StatPart* acc;                     // wave-specialised kernel: statistics go straight to the accumulators
     // EPI_DEC: conv bias -> BatchNorm(inference) -> LeakyReLU [-> + resid]
     const float* bias; const float* bn_s; const float* bn_rm; const float* bn_beta;
     const float* resid; int resid_up;   // resid_up: residual lives at half resolution (identity shortcut)
@@ -45,6 +45,7 @@ struct ConvParams {
     int w_resident;                              // filled by the launcher: whole weight panel LDS-resident (conv3x3 DB form)
     unsigned long long* stamps;   // diagnostic build (-DGSA_STAMP) only: per-phase cycle sums
     int dbg;                      // diagnostic build only: bit0 = stage pixel 0 everywhere (timing of a cache-resident input)
+    int prio;                     // experiment (GSA_PRIO): 1 = the wave OUTSIDE its MFMA phase gets the higher issue priority
     int bf16;                     // 1: bf16 MFMA mode -- wpk/wsc hold bf16 packs [..][tap][kq][16][4], operands rounded at staging
 };
 
@@ -68,7 +69,8 @@ struct FinalizeParams {
 
 // launches (all stream-ordered, no sync)
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);
-bool conv_uses_ws(const ConvParams& p, int epi, bool shortcut, int n);   // true: wave-specialised kernel, no partial rows
+bool conv_uses_ws(const ConvParams& p, int epi, bool shortcut, int n);
+bool conv_uses_wino(const ConvParams& p, int epi, bool shortcut);   // true: Winograd form (static rule: layer shape only)   // true: wave-specialised kernel, no partial rows
 hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);   // deconv4x4s2 / sub-pixel up+conv3x3
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s);
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);

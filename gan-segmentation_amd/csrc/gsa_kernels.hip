@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #ifdef GSA_DBG_HOOKS
         if (p.dbg & 16) return;      // timing-only: no MFMA phase
 #endif
-        __builtin_amdgcn_s_setprio(GSA_MFMA_PRIO);      // the wave in its MFMA phase wins the SIMD's issue slot
+        if (p.prio) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(GSA_MFMA_PRIO);      // the wave in its MFMA phase wins the SIMD's issue slot
         const float* a_img = sA + buf * (LH * RS);
         const float* b_img = sB + (wres ? cb_res : buf) * (Q * SEG);
         if constexpr (BF) {
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tap & 1][mt][cg], b2[tap & 1][nt][cg], acc[mt][nt], 0, 0, 0);
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (p.prio) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
             return;
         }
 #pragma unroll
@@ -614,8 +614,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
                             accs[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], bs[nt][cg], accs[mt][nt], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (p.prio) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
     };
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
 
     if constexpr (DB) {
         // items in flight: `tc/cb` is being multiplied out of LDS buffer it&1, `tr/cbr` sits in the
@@ -756,342 +757,319 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// conv3x3, WAVE-SPECIALISED form for the layers whose tiles are short (few 16-channel blocks):
-// 8 waves per workgroup, one workgroup per CU.  Waves 0-3 (one per SIMD) only read LDS and
-// issue MFMAs; waves 4-7 are the memory side: they prefetch the (tile, block) item two steps
-// ahead from HBM, apply AdaIN, write the LDS images one step ahead (double buffered), and run
-// the epilogue of finished tiles out of an LDS copy of the accumulators -- noise/bias/
-// LeakyReLU/statistics or bias/BN/LeakyReLU/residual, then 16-B stores that cover whole rows.
-// The MFMA waves never touch global memory, so no vmcnt wait ever sits in front of an MFMA;
-// the two sides meet at one s_barrier per item.  (Stamps of the one-workgroup-per-tile kernel
-// showed the load, MFMA and store phases of a whole generation of workgroups in lockstep.)
-// Statistics leave through per-wave shuffles and device-scope 64-bit atomics straight into the
-// accumulators finalize_kernel consumes (no partial rows).
-constexpr int kWsLoaderWaves = 8;   // memory-side waves per workgroup (two per SIMD)
-
-template <int NT, int EPI>
-__global__ __launch_bounds__(256 + 64 * kWsLoaderWaves) void conv3x3_ws(ConvParams p) {
-    constexpr int LT = 64 * kWsLoaderWaves;      // memory-side threads
-    constexpr int TH = 16, TW = 16, LH = 18, LW = 18, RS = LW * 16 + 8;
-    constexpr int Q = NT, COUT_T = 16 * Q, SEG = 9 * 256, NB4 = Q * SEG / 4;
-    constexpr int AIT = (LH * LW + LT - 1) / LT, BIT = (NB4 + LT - 1) / LT, FIT = (512 + LT - 1) / LT;   // FIT: AdaIN table <= 512 channels
-    constexpr int QL = 4 * Q;                    // channel quads per pixel = lanes per pixel in the epilogue
-    constexpr int EIT = 256 * QL / LT;           // epilogue passes: 256 px * QL quads / LT threads
+// conv3x3 (pad 1, stride 1, one source) in WINOGRAD F(2x2, 3x3) form on v_mfma_f32_16x16x4_f32.
+//
+//     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A      per 2x2 output tile: 16 products per (tile, c, o) instead of 36
+//
+// The sixteen "frequencies" f = 4i+j are sixteen independent GEMMs  M_f[tile][o] = sum_c V_f[tile][c] U_f[c][o]:
+// M = 16 Winograd tiles, N = 16 output channels, K = input channels -- 64 MFMAs per 16-channel block and 64 output
+// pixels where the direct form needs 144.  Canonical arithmetic: oracle/c/gsa_oracle.c conv3x3_wino (the transforms
+// are plain fp32 adds in a fixed order, each M_f is one k-ordered fmaf chain = the MFMA, U is computed in double on
+// the host and rounded once), so the result is reproduced BIT FOR BIT; DESIGN.md states the rule that selects the
+// form (layer shape only: plain 3x3 convs with outputs >= 32 px, fp32 mode).
+//
+// Workgroup = 4 waves on a 16x16 output tile x 16 output channels; wave w owns the 8x8 quadrant (w>>1, w&1) = 16
+// Winograd tiles.  Lane (i16, kq): tile (ty, tx) = (2*b3 + b1, 2*b2 + b0) of the quadrant (b = bits of i16) -- with
+// the row stride 18*16+4 floats every ds_read_b128 of the 4x4 input patch is bank-conflict free -- and k slot kq.
+// The C layout then gives a lane (channel = lane & 15, group = lane >> 4) the 2x2 tiles of ONE 4x4 output patch in
+// its four accumulator registers: after the output transform a lane holds four aligned x-quads, exactly the shape
+// the epilogue of conv3x3_mfma works on (in-lane statistics, quad transpose, 16-byte stores).
+// Staging (AdaIN on read, zero padding, double-buffered LDS image, prefetch two items ahead, resident or streamed
+// weight panel, direct statistics, XCD-aware tile walk) is the structure of conv3x3_mfma's double-buffered form.
+// blockIdx.y = output-channel group, so a resident panel never changes under a persistent workgroup.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvParams p) {
+    constexpr int NTHR = 256, LH = 18, LW = 18, RS = LW * 16 + 4;
+    constexpr int SEG = 16 * 256;                // U floats per (16 couts, 16-channel block): 16 frequencies x [ci][16][cg]
+    constexpr int NB4 = SEG / 4, BIT = NB4 / NTHR;
+    constexpr int AIT = (LH * LW + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nblk = p.C0 >> 4;
+    const bool wres = p.w_resident != 0;
     float* sA = smem;                            // [2][LH*RS]
-    float* sB = sA + 2 * LH * RS;                // [2][Q*SEG]
-    float* sOut = sB + 2 * Q * SEG;              // [2][256*COUT_T]  accumulators of a finished tile, [px][c]
-    f32x4* sAff = reinterpret_cast<f32x4*>(sOut + 2 * 256 * COUT_T);   // [2][C0] by sample parity
+    float* sB = sA + 2 * LH * RS;                // resident: [nblk][SEG]; streamed: [2][SEG]
+    f32x4* sAff = reinterpret_cast<f32x4*>(sB + (wres ? nblk : 2) * SEG);   // [2][16] (mean, A, B, -)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool mfma_wave = wave < 4;
     const int i16 = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.y;
 
+    // contiguous range of the group's tiles, order (n, ty, tx)
     const int chunk = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int w_begin = blockIdx.x * chunk;
+    const int w_begin = xcd_block(blockIdx.x, gridDim.x) * chunk;
     const int w_end = min(p.total_tiles, w_begin + chunk);
     if (w_begin >= w_end) return;
-    const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4;
-    const int total = (w_end - w_begin) * nblk;  // items of this workgroup
-    const bool has_aff = p.aff0 != nullptr;
-
-    if (mfma_wave) {
-        // =========================== MFMA side ===========================
-        const int wm = wave;
-        int abase[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) abase[mt] = (wm * 4 + (i16 >> 2)) * RS + (mt * 4 + (i16 & 3)) * 16 + kq * 4;
-        const int bbase = (kq * 16 + i16) * 4;
-        f32x4 acc[4][NT];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();                                   // B0: AdaIN tables written
-        __syncthreads();                                   // B1: item 0 staged
-        int tcount = 0;
-        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, ts_work = 0, ts_bar = 0;
-        (void)tk0; (void)tk1; (void)tk2; (void)ts_work; (void)ts_bar;
-        for (int i = 0; i <= total; ++i) {
-            TICK(tk0);
-#ifdef GSA_STAMP
-            if (p.dbg & 2) { TICK(tk1); __syncthreads(); TICK(tk2); continue; }   // timing-only: idle MFMA side
-#endif
-            if (i < total) {
-                const float* a_img = sA + (i & 1) * (LH * RS);
-                const float* b_img = sB + (i & 1) * (Q * SEG);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int toff = (tap / 3) * RS + (tap % 3) * 16;
-                    f32x4 a[4], b[NT];
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_img + abase[mt] + toff);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(b_img + bbase + nt * SEG + tap * 256);
-#pragma unroll
-                    for (int cg = 0; cg < 4; ++cg)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
-                }
-                if (i % nblk == nblk - 1) {
-                    // tile finished: hand the accumulators to the memory side, [px][channel]
-                    float* o = sOut + (tcount & 1) * (256 * COUT_T);
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                o[((wm * 4 + (lane >> 4)) * TW + mt * 4 + r) * COUT_T + nt * 16 + i16] = acc[mt][nt][r];
-                            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
-                    ++tcount;
-                }
-            }
-            TICK(tk1);
-            __syncthreads();
-            TICK(tk2);
-            TSUM(ts_work, tk0, tk1); TSUM(ts_bar, tk1, tk2);
-        }
-        TFLUSH(0, ts_work); TFLUSH(1, ts_bar);
-#ifdef GSA_STAMP
-        if (p.stamps && lane == 0) atomicAdd(&p.stamps[15], 1ull);
-#endif
-        return;
-    }
-
-    // =========================== memory side (waves 4-7) ===========================
-    const int ltid = tid - 256;
-    auto decode = [&](int w) {
-        WorkTile t;
-        const int tx = w % p.tiles_x;
-        int r = w / p.tiles_x;
-        const int ty = r % p.tiles_y;
-        r /= p.tiles_y;
-        t.g = r % p.groups;
-        t.n = r / p.groups;
-        t.y0 = ty * TH; t.x0 = tx * TW;
-        t.row = ty * p.tiles_x + tx;
-        return t;
+    struct Tile { int n, y0, x0, row; };
+    auto advance = [&](const Tile& t) {
+        Tile u = t;
+        u.x0 += 16; u.row += 1;
+        if (u.x0 == p.W) { u.x0 = 0; u.y0 += 16; if (u.y0 == p.H) { u.y0 = 0; u.row = 0; u.n += 1; } }
+        return u;
     };
-    auto item_tile = [&](int i) { return decode(w_begin + min(i, total - 1) / nblk); };
-    auto tile_pixels = [&](const WorkTile& t, TilePixel (&tp)[AIT]) {
+    auto is_edge = [&](const Tile& t) { return t.y0 == 0 || t.x0 == 0 || t.y0 + 16 == p.H || t.x0 + 16 == p.W; };
+    int t_ly[AIT], t_lx[AIT], t_lds[AIT];
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+        const int idx = tid + it * NTHR;
+        t_ly[it] = idx / LW - 1; t_lx[it] = idx % LW - 1;
+        t_lds[it] = idx < LH * LW ? (idx / LW) * RS + (idx % LW) * 16 : -1;
+    }
+    auto tile_pixels = [&](const Tile& t, TilePixel (&tp)[AIT]) {
 #pragma unroll
         for (int it = 0; it < AIT; ++it) {
-            const int idx = ltid + it * LT;
-            const int ly = idx / LW, lx = idx % LW;
-            const int gy = t.y0 - 1 + ly, gx = t.x0 - 1 + lx;
-            const bool stage = idx < LH * LW;
-            const bool inside = stage && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            tp[it].lds = stage ? ly * RS + lx * 16 : -1;
-            tp[it].pix = inside ? (t.n * p.Hs + gy) * p.Ws + gx : -1;
-#ifdef GSA_STAMP
-            if ((p.dbg & 1) && inside) tp[it].pix = lx & 1;      // timing-only: every load hits the same two pixels
-#endif
+            const int gy = t.y0 + t_ly[it], gx = t.x0 + t_lx[it];
+            const bool inside = t_lds[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            tp[it].lds = t_lds[it];
+            tp[it].pix = inside ? (t.n * p.H + gy) * p.W + gx : -1;
         }
     };
-    // D-deep register ring of prefetched items: with one workgroup per CU the bytes in flight
-    // per CU are what the prefetch depth makes them (Little's law: ~30 KB per item, HBM latency
-    // of several microseconds under load), so one item ahead is not enough
-    constexpr int D = 3;
-    f32x4 ra[D][AIT][4], rb[D][BIT];
-    TilePixel tps[D][AIT];
-    WorkTile tws[D];
-    auto load_item = [&](int i, f32x4 (&a)[AIT][4], f32x4 (&b)[BIT], TilePixel (&tp)[AIT], WorkTile& t) {
-        t = item_tile(i);
-        tile_pixels(t, tp);
-        const int cb = min(i, total - 1) % nblk;
-        const bool first = cb < nblk0;
-        const float* src = first ? p.src0 : p.src1;
-        const int Cs = first ? p.C0 : p.C1;
-        const int coff = (first ? cb : cb - nblk0) * 16;
+    // A operand: the 4x4 input patch of this lane's Winograd tile (halo coordinates), k slot kq
+    const int wty = ((i16 >> 3) & 1) * 2 + ((i16 >> 1) & 1), wtx = ((i16 >> 2) & 1) * 2 + (i16 & 1);
+    const int pbase = ((wave >> 1) * 8 + 2 * wty) * RS + ((wave & 1) * 8 + 2 * wtx) * 16 + kq * 4;
+    const int bbase = (kq * 16 + i16) * 4;
+
+    f32x4 acc[16];
 #pragma unroll
-        for (int it = 0; it < AIT; ++it) load_pixel(a[it], src, Cs, coff, tp[it]);
+    for (int f = 0; f < 16; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool has_aff = p.aff0 != nullptr;
+    f32x4 ra[AIT][4], rb[BIT], rf;
+    const float* wgrp = p.wpk + (size_t)g * nblk * SEG;      // U panel of this output-channel group
+    auto load_item = [&](const Tile& t, int cb, const TilePixel (&tp)[AIT]) {
 #pragma unroll
-        for (int j = 0; j < BIT; ++j) {
-            const int k = min(ltid + j * LT, NB4 - 1);
-            const int q = k / (SEG / 4), r = k % (SEG / 4);
-            b[j] = reinterpret_cast<const f32x4*>(p.wpk + ((size_t)(t.g * Q + q) * nblk + cb) * SEG)[r];
+        for (int it = 0; it < AIT; ++it) load_pixel(ra[it], p.src0, p.C0, cb * 16, tp[it]);
+        if (!wres) {
+#pragma unroll
+            for (int j = 0; j < BIT; ++j) rb[j] = reinterpret_cast<const f32x4*>(wgrp + (size_t)cb * SEG)[tid + j * NTHR];
         }
+        if (has_aff) rf = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0 + cb * 16)[tid & 15];
     };
-    auto copy_aff = [&](int n) {     // AdaIN table of sample n -> sAff[n & 1]
-#pragma unroll
-        for (int j = 0; j < FIT; ++j) {
-            const int k = min(ltid + j * LT, p.C0 - 1);
-            sAff[(n & 1) * p.C0 + k] = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)n * p.C0)[k];
-        }
+    auto write_aff_item = [&](int slot) {
+        if (has_aff && tid < 16) sAff[slot * 16 + tid] = rf;
     };
-    auto write_item = [&](int i, f32x4 (&a)[AIT][4], f32x4 (&b)[BIT], const TilePixel (&tp)[AIT], const WorkTile& t) {
-        const int cb = i % nblk;
-        float* a_img = sA + (i & 1) * (LH * RS);
-        if (cb < nblk0 && has_aff) {
-            const float4* tab = reinterpret_cast<const float4*>(sAff + (t.n & 1) * p.C0) + cb * 16;
+    auto write_item = [&](const TilePixel (&tp)[AIT], bool edge, int buf) {
+        float* a_img = sA + buf * (LH * RS);
+        const float4* tab = reinterpret_cast<const float4*>(sAff) + buf * 16;
+        if (has_aff) {
+            if (edge) {
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<true>(a_img, a[it], tab, tp[it]);
+                for (int it = 0; it < AIT; ++it) store_pixel<true, false, true>(a_img, ra[it], tab, tp[it]);
+            } else {
+#pragma unroll
+                for (int it = 0; it < AIT; ++it) store_pixel<true, false, false>(a_img, ra[it], tab, tp[it]);
+            }
+        } else if (edge) {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) store_pixel<false, false, true>(a_img, ra[it], tab, tp[it]);
         } else {
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<false>(a_img, a[it], reinterpret_cast<const float4*>(sAff), tp[it]);
+            for (int it = 0; it < AIT; ++it) store_pixel<false, false, false>(a_img, ra[it], tab, tp[it]);
         }
-        f32x4* b_img = reinterpret_cast<f32x4*>(sB + (i & 1) * (Q * SEG));
+        if (!wres) {
 #pragma unroll
-        for (int j = 0; j < BIT; ++j) b_img[min(ltid + j * LT, NB4 - 1)] = b[j];
+            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * SEG)[tid + j * NTHR] = rb[j];
+        }
     };
 
-    // epilogue mapping: lane bits [0:1] = x & 3 (so an x-quad sits in 4 adjacent lanes and is
-    // summed with DPP quad permutes), next log2(QL) bits = channel quad, the rest = pixel group:
-    // pass k covers pixel groups k*GPP + rem, group pg -> row pg>>2, columns 4*(pg&3)..+3.
-    // A wave still writes whole rows: 16 pixels x 64 B (or 8 x 128 B) contiguous.
-    const int xl = ltid & 3, equad = (ltid >> 2) % QL, erem = (ltid >> 2) / QL;
-    constexpr int GPP = LT / 4 / QL;             // pixel groups per pass
-    unsigned long long st1 = 0, st2 = 0;         // running statistics of channel 4*equad + xl of this thread
-    int stat_n = -1, stat_g = 0;
-    auto flush_stats = [&]() {
-        if (EPI != EPI_SYNTH || stat_n < 0) return;
-        // lanes that share (xl, equad) are 4*QL apart: fold them, then one atomic pair per channel and wave
-#pragma unroll
-        for (int m = 4 * QL; m < 64; m <<= 1) {
-            st1 += shfl_xor_u64(st1, m);
-            st2 += shfl_xor_u64(st2, m);
-        }
-        if (lane < 4 * QL) {
-            StatPart* a = p.acc + (size_t)stat_n * p.Cout + stat_g * COUT_T + equad * 4 + xl;
-            atomicAdd(&a->s1, st1);
-            atomicAdd(&a->s2, st2);
-        }
-        st1 = 0; st2 = 0;
-    };
-
-    // ---- prologue: ring set j % D holds item j
-    load_item(0, ra[0], rb[0], tps[0], tws[0]);
-    int aff_n = tws[0].n;             // newest sample whose AdaIN table is in sAff
-    if (has_aff) copy_aff(aff_n);
-    __syncthreads();                                       // B0
-    write_item(0, ra[0], rb[0], tps[0], tws[0]);
-#pragma unroll
-    for (int j = 1; j <= D; ++j) {
-        load_item(j, ra[j % D], rb[j % D], tps[j % D], tws[j % D]);
-        if (has_aff && tws[j % D].n != aff_n) { aff_n = tws[j % D].n; copy_aff(aff_n); }
-    }
-    __syncthreads();                                       // B1
-
-    // epilogue inputs (noise / residual) are prefetched one iteration ahead, the per-channel
-    // constants are reloaded only when the channel group changes
-    float nzv[EPI == EPI_SYNTH ? EIT : 1];
-    f32x4 rr[EPI == EPI_DEC ? EIT : 1];
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
-    int const_g = -1;
+    // ---- epilogue geometry: lane -> (channel = lane & 15, 4x4 output patch (b3, b2) = lane >> 4 of the wave's quadrant);
+    // registers after the output transform: row r of the patch as an x-quad
+    const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;     // quad-transposed store layout
+    const int prow0 = (wave >> 1) * 8 + ((lane >> 5) & 1) * 4, pcol0 = (wave & 1) * 8 + ((lane >> 4) & 1) * 4;
+    const int co = g * 16 + i16;
+    const unsigned lane_out = (unsigned)((prow0 * p.W + pcol0 + xj) * p.Cout + g * 16 + cq4);
+    const unsigned lane_nz = (unsigned)(prow0 * p.W + pcol0);
     const bool has_resid = EPI == EPI_DEC && p.resid != nullptr;
-    auto prefetch_epilogue = [&](const WorkTile& t) {
-        const int co = t.g * COUT_T + equad * 4;
+    const int ru = p.resid_up;
+    const int res_cs0 = p.resid1 ? p.res_c0 : p.Cout, res_cs1 = p.Cout - p.res_c0;
+    const bool res_second = p.resid1 != nullptr && g * 16 >= p.res_c0;     // a 16-channel group never straddles the split
+    const float* res_src = res_second ? p.resid1 : p.resid;
+    const int res_cs = res_second ? res_cs1 : res_cs0;
+    const int res_ch = res_second ? g * 16 - p.res_c0 : g * 16;
+    float4 nzs[EPI == EPI_SYNTH ? 4 : 1];
+    f32x4 rr[EPI == EPI_DEC ? 4 : 1];
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+    if (EPI == EPI_SYNTH) { e0 = p.nscale[co]; e1 = p.nbias[co]; }
+    if (EPI == EPI_DEC) { e0 = p.bias[co]; e1 = p.bn_rm[co]; e2 = p.bn_s[co]; e3 = p.bn_beta[co]; }
+    auto epilogue_loads = [&](const Tile& tc) {
         if (EPI == EPI_SYNTH) {
+            const float* nz = p.noise + ((size_t)(tc.n * p.H + tc.y0) * p.W + tc.x0) + lane_nz;
 #pragma unroll
-            for (int k = 0; k < EIT; ++k) {
-                const int pg = k * GPP + erem;
-                nzv[k] = p.noise[(size_t)(t.n * p.H + t.y0 + (pg >> 2)) * p.W + t.x0 + (pg & 3) * 4 + xl];
-            }
+            for (int r = 0; r < 4; ++r) nzs[r] = *reinterpret_cast<const float4*>(nz + r * p.W);
         }
         if (EPI == EPI_DEC && has_resid) {
+            const int Wr = p.W >> ru;
 #pragma unroll
-            for (int k = 0; k < EIT; ++k) {
-                const int pg = k * GPP + erem;
-                const int y = t.y0 + (pg >> 2), x = t.x0 + (pg & 3) * 4 + xl;
-                const size_t rp = p.resid_up ? (size_t)(t.n * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1)
-                                             : (size_t)(t.n * p.H + y) * p.W + x;
-                rr[k] = *reinterpret_cast<const f32x4*>(p.resid + rp * p.Cout + co);
+            for (int r = 0; r < 4; ++r) {
+                const size_t rpix = (size_t)(tc.n * (p.H >> ru) + ((tc.y0 + prow0 + r) >> ru)) * Wr + ((tc.x0 + pcol0 + xj) >> ru);
+                rr[r] = *reinterpret_cast<const f32x4*>(res_src + rpix * res_cs + res_ch + cq4);
+            }
+        }
+    };
+    const bool stats_direct = EPI == EPI_SYNTH && p.stats_direct;
+    unsigned long long dI1 = 0ull, dI2 = 0ull;
+    auto flush_stats = [&](const Tile& t) {
+        unsigned long long I1 = dI1, I2 = dI2;
+        I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
+        I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
+        if (lane < 16) {
+            StatPart* a = p.partials + ((size_t)t.n * p.prow + (blockIdx.x & (kDirectRows - 1))) * p.Cout + co;
+            atomicAdd(&a->s1, I1);
+            atomicAdd(&a->s2, I2);
+        }
+        dI1 = dI2 = 0ull;
+    };
+    auto epilogue = [&](const Tile& tc) {
+        // output transform Y = A^T M A: rows s0 = (M0+M1)+M2, s1 = (M1-M2)-M3, then the same along the columns;
+        // register component = Winograd tile (b1, b0) of the lane's 4x4 patch
+        f32x4 s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = (acc[j] + acc[4 + j]) + acc[8 + j];
+            s1[j] = (acc[4 + j] - acc[8 + j]) - acc[12 + j];
+        }
+        const f32x4 y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];     // tile row 0: x = 0, 1
+        const f32x4 y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];     // tile row 1
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned long long I1 = 0, I2 = 0;
+        const size_t ubase = ((size_t)(tc.n * p.H + tc.y0) * p.W + tc.x0) * p.Cout;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // patch row r = 2*b1 + i: tiles (b1, 0) and (b1, 1), tile row i
+            const int b1 = r >> 1;
+            const f32x4& ya = (r & 1) ? y10 : y00;
+            const f32x4& yb = (r & 1) ? y11 : y01;
+            float v[4] = {ya[2 * b1], yb[2 * b1], ya[2 * b1 + 1], yb[2 * b1 + 1]};
+            if (EPI == EPI_SYNTH) {
+                const float nzv[4] = {nzs[r].x, nzs[r].y, nzs[r].z, nzs[r].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = e0 * nzv[k];
+                    v[k] = lrelu((v[k] + t) + e1);
+                }
+                const float sq = (v[0] + v[1]) + (v[2] + v[3]);
+                const float qq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                I1 += to_fixed(sq, kStatScale1);
+                I2 += to_fixed(qq, kStatScale2);
+            }
+            if (EPI == EPI_DEC) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float yv = v[k] + e0;
+                    v[k] = lrelu(fmaf(yv - e1, e2, e3));
+                }
+            }
+            f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
+            if (EPI == EPI_DEC && has_resid) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vt[k] = rr[r][k] + vt[k];
+            }
+            *reinterpret_cast<f32x4*>(p.out + ubase + (size_t)r * p.W * p.Cout + lane_out) = vt;
+        }
+        if (EPI == EPI_SYNTH && stats_direct) {
+            dI1 += I1; dI2 += I2;
+        } else if (EPI == EPI_SYNTH) {
+            I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
+            I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
+            if (lane < 16) {
+                StatPart sp; sp.s1 = I1; sp.s2 = I2;
+                p.partials[((size_t)tc.n * p.prow + tc.row * 4 + wave) * p.Cout + co] = sp;
             }
         }
     };
 
-    unsigned long long lk0 = 0, lk1 = 0, lk2 = 0, lk3 = 0, lk4 = 0, ls_w = 0, ls_l = 0, ls_e = 0, ls_b = 0;
-    (void)lk0; (void)lk1; (void)lk2; (void)lk3; (void)lk4; (void)ls_w; (void)ls_l; (void)ls_e; (void)ls_b;
-    for (int i0 = 0; i0 <= total; i0 += D) {
+    auto wino_item = [&](int buf, int cb_res) {
+        __builtin_amdgcn_s_setprio(GSA_MFMA_PRIO);
+        const float* a_img = sA + buf * (LH * RS) + pbase;
+        const float* b_img = sB + (wres ? cb_res : buf) * SEG + bbase;
+        // input transform V = B^T d B on the lane's 4x4 patch, four channels (cg) per vector:
+        //   rows  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3;   columns: the same four forms
+        f32x4 V[16];
 #pragma unroll
-      for (int ph = 0; ph < D; ++ph) {
-        const int i = i0 + ph;
-        if (i > total) break;                 // wave-uniform; keeps the barrier count equal to the MFMA side
-        constexpr int kDummy = 0; (void)kDummy;
-        const int set = (ph + 1) % D;         // static: ring set of item i+1 (i0 is a multiple of D)
-        TICK(lk0);
-        // L1: stage item i+1 (its loads were issued D iterations ago)
-        if (i + 1 < total) write_item(i + 1, ra[set], rb[set], tps[set], tws[set]);
-        TICK(lk1);
-        // L3: prefetch item i+1+D into the ring set just freed
-        load_item(i + 1 + D, ra[set], rb[set], tps[set], tws[set]);
-        if (has_aff && i + 1 + D < total && tws[set].n != aff_n) { aff_n = tws[set].n; copy_aff(aff_n); }   // rare
-        TICK(lk2);
-        // the tile that finished in iteration i-1 (if any)
-        const bool have_epi = i >= 1 && (i - 1) % nblk == nblk - 1;
-        const WorkTile te = decode(w_begin + (max(i, 1) - 1) / nblk);
-        if (have_epi && te.g != const_g) {       // rare: per-channel constants of a new channel group
-            const int co = te.g * COUT_T + equad * 4;
-            if (EPI == EPI_SYNTH) {
-                c0 = *reinterpret_cast<const f32x4*>(p.nscale + co);
-                c1 = *reinterpret_cast<const f32x4*>(p.nbias + co);
-            }
-            if (EPI == EPI_DEC) {
-                c0 = *reinterpret_cast<const f32x4*>(p.bias + co);
-                c1 = *reinterpret_cast<const f32x4*>(p.bn_rm + co);
-                c2 = *reinterpret_cast<const f32x4*>(p.bn_s + co);
-                c3 = *reinterpret_cast<const f32x4*>(p.bn_beta + co);
-            }
-            const_g = te.g;
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(a_img + 0 * RS + c * 16);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(a_img + 1 * RS + c * 16);
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(a_img + 2 * RS + c * 16);
+            const f32x4 d3 = *reinterpret_cast<const f32x4*>(a_img + 3 * RS + c * 16);
+            V[0 * 4 + c] = d0 - d2;
+            V[1 * 4 + c] = d1 + d2;
+            V[2 * 4 + c] = d2 - d1;
+            V[3 * 4 + c] = d1 - d3;
         }
-        // L4: epilogue of the finished tile out of sOut
-        if (have_epi) {
-            if (EPI == EPI_SYNTH && (te.n != stat_n || te.g != stat_g)) { flush_stats(); stat_n = te.n; stat_g = te.g; }
-            const float* o = sOut + (((i - 1) / nblk) & 1) * (256 * COUT_T);
-            const int co = te.g * COUT_T + equad * 4;
 #pragma unroll
-            for (int k = 0; k < EIT; ++k) {
-                const int pg = k * GPP + erem;
-                const int yl = pg >> 2, xt = (pg & 3) * 4 + xl;
-                const int y = te.y0 + yl, x = te.x0 + xt;
-                f32x4 v = *reinterpret_cast<const f32x4*>(o + (yl * TW + xt) * COUT_T + equad * 4);
-                if (EPI == EPI_SYNTH) {
-                    float s4 = 0.f, q4 = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float t = c0[j] * nzv[k];
-                        v[j] = lrelu((v[j] + t) + c1[j]);
-                        // x-quad = 4 adjacent lanes: (v0+v1)+(v2+v3) via quad_perm [1,0,3,2] then [2,3,0,1];
-                        // commutativity makes the result the same bits in all four lanes
-                        const float sq = v[j] * v[j];
-                        const float t1 = v[j] + dpp_quad<0xB1>(v[j]);
-                        const float u1 = sq + dpp_quad<0xB1>(sq);
-                        const float t2 = t1 + dpp_quad<0x4E>(t1);
-                        const float u2 = u1 + dpp_quad<0x4E>(u1);
-                        if (j == 0) { s4 = t2; q4 = u2; }
-                        else { s4 = xl == j ? t2 : s4; q4 = xl == j ? u2 : q4; }   // lane xl keeps channel 4*equad+xl
-                    }
-                    st1 += to_fixed(s4, kStatScale1);
-                    st2 += to_fixed(q4, kStatScale2);
-                }
-                if (EPI == EPI_DEC) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float yv = v[j] + c0[j];
-                        v[j] = lrelu(fmaf(yv - c1[j], c2[j], c3[j]));
-                        if (has_resid) v[j] = rr[k][j] + v[j];
-                    }
-                }
-                *reinterpret_cast<f32x4*>(p.out + ((size_t)(te.n * p.H + y) * p.W + x) * p.Cout + co) = v;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 t0 = V[i * 4 + 0], t1 = V[i * 4 + 1], t2 = V[i * 4 + 2], t3 = V[i * 4 + 3];
+            V[i * 4 + 0] = t0 - t2;
+            V[i * 4 + 1] = t1 + t2;
+            V[i * 4 + 2] = t2 - t1;
+            V[i * 4 + 3] = t1 - t3;
         }
-        // inputs of the NEXT epilogue: the tile whose last block is item i finishes in this iteration
-        // and is consumed in iteration i+1, i.e. these loads have a whole iteration to land
-        if (i < total && i % nblk == nblk - 1) prefetch_epilogue(item_tile(i));
-        TICK(lk3);
-        __syncthreads();
-        TICK(lk4);
-        TSUM(ls_w, lk0, lk1); TSUM(ls_l, lk1, lk2); TSUM(ls_e, lk2, lk3); TSUM(ls_b, lk3, lk4);
-      }
+        // sixteen GEMMs: per frequency one chain over the block's channels (cg ascending), four frequencies interleaved
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            f32x4 b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_img + (fb * 4 + j) * 256);
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[fb * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[fb * 4 + j][cg], b[j][cg], acc[fb * 4 + j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- items (tile, channel block): item `it` is multiplied out of LDS buffer it & 1, item it+1 sits in the
+    // prefetch registers, item it+2 is being loaded
+    const int total_items = (w_end - w_begin) * nblk;
+    Tile tc, tr;
+    {
+        const int tx = w_begin % p.tiles_x, r = w_begin / p.tiles_x;
+        tc.x0 = tx * 16; tc.y0 = (r % p.tiles_y) * 16; tc.n = r / p.tiles_y; tc.row = (r % p.tiles_y) * p.tiles_x + tx;
     }
-    TFLUSH(2, ls_w); TFLUSH(3, ls_l); TFLUSH(4, ls_e); TFLUSH(5, ls_b);
-    flush_stats();
+    int cb = 0, cbr = 0;
+    TilePixel tpr[AIT];
+    auto next_item = [&](int i, Tile& t, int& cbi, TilePixel (&tp)[AIT]) {
+        if (i + 1 >= total_items) return;
+        if (++cbi == nblk) { cbi = 0; t = advance(t); tile_pixels(t, tp); }
+    };
+    tile_pixels(tc, tpr);
+    if (wres) {
+        for (int cbk = 0; cbk < nblk; ++cbk) {
+#pragma unroll
+            for (int j = 0; j < BIT; ++j) rb[j] = reinterpret_cast<const f32x4*>(wgrp + (size_t)cbk * SEG)[tid + j * NTHR];
+#pragma unroll
+            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + cbk * SEG)[tid + j * NTHR] = rb[j];
+        }
+    }
+    load_item(tc, cb, tpr);
+    if (has_aff) {
+        write_aff_item(0);
+        __syncthreads();
+    }
+    write_item(tpr, is_edge(tc), 0);
+    tr = tc; cbr = cb;
+    next_item(0, tr, cbr, tpr);
+    load_item(tr, cbr, tpr);
+    write_aff_item(1);
+    __syncthreads();
+    for (int it = 0; it < total_items; ++it) {
+        const bool has_next = it + 1 < total_items;
+        if (has_next) write_item(tpr, is_edge(tr), (it + 1) & 1);
+        if (cb == nblk - 1) epilogue_loads(tc);
+        Tile t2 = tr; int cb2 = cbr;
+        next_item(it + 1, t2, cb2, tpr);
+        load_item(t2, cb2, tpr);
+        wino_item(it & 1, cb);
+        if (cb == nblk - 1) {
+            epilogue(tc);
+            if (stats_direct && (!has_next || tr.n != tc.n)) flush_stats(tc);
+        }
+        write_aff_item(it & 1);
+        __syncthreads();
+        tc = tr; cb = cbr; tr = t2; cbr = cb2;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1527,9 +1505,12 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
         }
     };
     auto mfma_item = [&](int buf, int ci, int it) {
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) mfma_block(buf, kb, WST ? (it & 1) : ci * KB + kb);
+        if (p.prio) __builtin_amdgcn_s_setprio(3);
     };
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     auto epilogue = [&](const Tile& t) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -2320,58 +2301,73 @@ static hipError_t launch_conv_e(const ConvParams& p, int epi, bool sc, int n, hi
                   : launch_conv_b<TH, TW, WM, WN, NT, false>(p, epi, sc, n, s);
 }
 
-template <int NT, int EPI>
-static hipError_t launch_conv_ws_t(const ConvParams& p, int n, hipStream_t s) {
-    constexpr int Q = NT, COUT_T = 16 * Q;
-    const size_t lds = sizeof(float) * (2 * 18 * (18 * 16 + 8) + 2 * Q * 9 * 256 + 2 * 256 * COUT_T) + (p.aff0 ? 2 * sizeof(float4) * p.C0 : 0);
-    auto kern = conv3x3_ws<NT, EPI>;
+// ---- Winograd form ---------------------------------------------------------------------------------------
+// The rule is static (layer shape and arithmetic mode only, never the batch size): it is part of the canonical
+// arithmetic and the oracle applies the same one (oracle/c/gsa_oracle.c use_wino).
+bool conv_uses_wino(const ConvParams& p, int epi, bool sc) {
+    static const bool enabled = !(getenv("GSA_WINO") && atoi(getenv("GSA_WINO")) == 0);
+    return enabled && p.wino != nullptr && !p.bf16 && !sc && !p.up && p.src1 == nullptr && p.C1 == 0 && epi != EPI_RAW &&
+           p.H >= 32 && p.W >= 32 && p.H % 16 == 0 && p.W % 16 == 0 && p.Cout % 16 == 0 && p.C0 % 16 == 0;
+}
+
+template <int EPI>
+static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
+    constexpr int RS = 18 * 16 + 4, SEG = 16 * 256;
+    const int nblk = p.C0 / 16;
+    const bool wres = (size_t)nblk * SEG * sizeof(float) <= 36 * 1024;      // whole panel of the group resident (<= 32 input channels)
+    const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * SEG) + 32 * sizeof(float4);
+    auto kern = conv3x3_wino<EPI>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
-    int num_cus = 0;
+    int num_cus = 0, wgs_per_cu = 0;
     {
         std::lock_guard<std::mutex> lk(g_launch_mu);
-        hipError_t e = prepare_kernel(kern, states[p.device]);
+        LaunchState& st = states[p.device];
+        hipError_t e = prepare_kernel(kern, st);
         if (e != hipSuccess) return e;
         num_cus = device_cus(p.device);
+        for (int i = 0; i < st.occ_n; ++i)
+            if (st.occ_lds[i] == lds) wgs_per_cu = st.occ_k[i];
+        if (!wgs_per_cu) {
+            int k = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, reinterpret_cast<const void*>(kern), 256, lds);
+            if (e != hipSuccess) return e;
+            wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
+            if (st.occ_n < 8) { st.occ_lds[st.occ_n] = lds; st.occ_k[st.occ_n] = wgs_per_cu; ++st.occ_n; }
+            if (getenv("GSA_VERBOSE")) fprintf(stderr, "gsa: conv3x3_wino<%d> lds %zu B%s -> %d workgroups/CU\n", EPI, lds, wres ? " (resident weights)" : "", k);
+        }
     }
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
     ConvParams q = p;
+    q.wpk = p.wino;
+    q.w_resident = wres ? 1 : 0;
     q.tiles_x = p.W / 16;
     q.tiles_y = p.H / 16;
-    q.groups = p.Cout / COUT_T;
-    q.prow = 0;
-    q.total_tiles = q.tiles_x * q.tiles_y * q.groups * n;
-    const int grid = q.total_tiles < num_cus ? q.total_tiles : num_cus;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + 64 * kWsLoaderWaves), lds, s, q);
+    q.groups = p.Cout / 16;
+    q.prow = q.tiles_x * q.tiles_y * 4;
+    q.total_tiles = q.tiles_x * q.tiles_y * n;         // per output-channel group
+    // persistent workgroups for short tiles (<= 2 channel blocks); a workgroup stays inside its channel group
+    const int slots = std::max(1, num_cus * wgs_per_cu / q.groups);
+    const bool persistent = p.C0 <= 32 && q.total_tiles > slots;
+    const int gx = persistent ? slots : q.total_tiles;
+    static const bool direct_enabled = !(getenv("GSA_STATS_DIRECT") && atoi(getenv("GSA_STATS_DIRECT")) == 0);
+    q.stats_direct = (direct_enabled && EPI == EPI_SYNTH && persistent && p.partials != nullptr) ? 1 : 0;
+    if (q.stats_direct) {
+        q.prow = kDirectRows;
+        hipError_t e = hipMemsetAsync(p.partials, 0, sizeof(StatPart) * (size_t)n * kDirectRows * p.Cout, s);
+        if (e != hipSuccess) return e;
+    }
+    if (p.stat_rows_host) *p.stat_rows_host = q.prow;
+    hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256), lds, s, q);
     return hipGetLastError();
-}
-
-// The wave-specialised kernel is used where tiles are short and plentiful.
-bool conv_uses_ws(const ConvParams& p, int epi, bool sc, int n) {
-    // EXPERIMENTAL, off by default (GSA_WS=1 enables): measured slower than the one-workgroup-per-tile
-    // kernel on MI355X -- with K = 144 per output the memory side's VALU/LDS work per item equals the
-    // MFMA time and the two sides contend for the SIMD's issue slots (stamps in DESIGN.md section 4).
-    static const bool enabled = getenv("GSA_WS") && atoi(getenv("GSA_WS")) != 0;
-    if (!enabled) return false;
-    if (sc || epi == EPI_RAW || p.up || p.H < 64) return false;
-    if (p.Cout % 16 || p.Cout > 32) return false;                  // NT 1 or 2 with COUT_T == Cout
-    if ((p.C0 + p.C1) > 64 || (p.aff0 && p.C0 > 512)) return false;
-    const long tiles = (long)(p.H / 16) * (p.W / 16) * n;
-    return tiles >= 1024;   // (H >= 64: >= 16 tiles per sample, more than the prefetch depth -- see the AdaIN table parity)
-}
-
-hipError_t launch_conv3x3_ws(const ConvParams& p, int epi, int n, hipStream_t s) {
-    const int nt = p.Cout / 16;
-    if (nt == 1 && epi == EPI_SYNTH) return launch_conv_ws_t<1, EPI_SYNTH>(p, n, s);
-    if (nt == 1 && epi == EPI_DEC) return launch_conv_ws_t<1, EPI_DEC>(p, n, s);
-    if (nt == 2 && epi == EPI_SYNTH) return launch_conv_ws_t<2, EPI_SYNTH>(p, n, s);
-    if (nt == 2 && epi == EPI_DEC) return launch_conv_ws_t<2, EPI_DEC>(p, n, s);
-    return hipErrorInvalidValue;
 }
 
 // exact C++ name of the instantiation launch_conv3x3 picks (profile labels spell kernels as rocprofv3 prints them)
 const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     static thread_local char buf[128];
+    if (conv_uses_wino(p, epi, sc)) {
+        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d>(gsa::ConvParams)", epi);
+        return buf;
+    }
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
     snprintf(buf, sizeof buf, "void gsa::conv3x3_mfma<%d, %d, %d, %d, %d, %d, %s, %s>(gsa::ConvParams)", c.th, c.th, c.wm, c.wn, c.nt,
              epi, sc ? "true" : "false", p.bf16 ? "true" : "false");
@@ -2380,7 +2376,7 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
 
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     if (p.H != p.W || (p.H & (p.H - 1)) || p.H < 4 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
-    if (!p.bf16 && conv_uses_ws(p, epi, sc, n)) return launch_conv3x3_ws(p, epi, n, s);
+    if (conv_uses_wino(p, epi, sc)) return epi == EPI_SYNTH ? launch_wino_t<EPI_SYNTH>(p, n, s) : launch_wino_t<EPI_DEC>(p, n, s);
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
 #define GSA_GEOM(TH, WM, WN, NT) \
     if (c.th == TH && c.wm == WM && c.wn == WN && c.nt == NT) return launch_conv_e<TH, TH, WM, WN, NT>(p, epi, sc, n, s);

@@ -84,6 +84,7 @@ typedef struct {
     float* nscale[2];
     float* nbias[2];
     float* w2;      /* packed conv_2 */
+    float* w2u;     /* conv_2 in Winograd form (pack_wino), used when use_wino() */
     float* aff_w[2];/* effective (2C, L) row-major */
     float* aff_b[2];
     float* gamma[2];
@@ -93,11 +94,13 @@ typedef struct {
 typedef struct {
     int F, I;        /* cvt: I -> F */
     float* cvt_w;    /* packed */
+    float* cvt_u;    /* Winograd form */
     float* cvt_b; float *cvt_s, *cvt_rm, *cvt_beta; /* bias; BN scale, running_mean, beta */
     int in_c, cs;    /* main block */
     int is_last, has_sc;
     float *a_w, *a_b, *a_s, *a_rm, *a_beta;
     float *b_w, *b_b, *b_s, *b_rm, *b_beta;
+    float* b_u;      /* conv b in Winograd form */
     float *sc_w, *sc_b;  /* sc_w packed [c][o] */
     float *f_w, *f_b;    /* final conv packed */
 } dec_level;
@@ -233,6 +236,52 @@ static float* pack_upconv(const float* w, int O, int I, float std, int use_std, 
     return out;
 }
 
+/* ---- Winograd F(2x2, 3x3) form of the plain 3x3 convolutions (Lavin & Gray 2016) -------------------------------
+ * Rule (static, by layer shape only -- never by batch size): a 3x3 stride-1 convolution WITHOUT upsample-on-read
+ * whose output is >= 32 px on a side is evaluated, in fp32 mode, as
+ *     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A          per 2x2 output tile, 16 products per (tile, c, o)
+ * instead of 36: 2.25x fewer multiplications.  Canonical arithmetic (every fp32 op rounded, nothing contracted):
+ *   weights    U = G g G^T evaluated in DOUBLE on the effective fp32 weights, rounded to fp32 once;
+ *   input      t = B^T d (rows), V = t B (columns):  t0=d0-d2, t1=d1+d2, t2=d2-d1, t3=d1-d3  (d = AdaIN-applied,
+ *              zero outside the image), the same four forms along the columns;
+ *   products   M[f] = fmaf chain over the input channels ascending (16-channel blocks, as everywhere), per
+ *              frequency f = 4i+j separately -- bitwise what v_mfma_f32_16x16x4_f32 produces;
+ *   output     s0=(M0+M1)+M2, s1=(M1-M2)-M3 along the rows, the same two forms along the columns.
+ * The result differs from the 9-tap chain by a few fp32 ulps of the intermediate magnitudes; oracle/ref_semantic.py
+ * keeps the reference's 9-tap order and bounds the difference (tests: <= 1e-3 on rgb and logits at full size). */
+static int g_wino_enabled = -1;
+static int use_wino(int H, int W, int up, int bf) {
+    if (g_wino_enabled < 0) { const char* e = getenv("GSAO_WINO"); g_wino_enabled = !(e && atoi(e) == 0); }
+    return g_wino_enabled && !bf && !up && H >= 32 && W >= 32 && H % 16 == 0 && W % 16 == 0;
+}
+
+/* conv OIHW (O,I,3,3) -> U packed [(cb*16 + f)*CB + c][O], f = 4*i + j */
+static float* pack_wino(const float* w, int O, int I, float std, int use_std, float lr) {
+    float* out = (float*)malloc(sizeof(float) * (size_t)O * I * 16);
+    for (int cb = 0; cb < I / CB; ++cb)
+        for (int ci = 0; ci < CB; ++ci)
+            for (int o = 0; o < O; ++o) {
+                const float* wk = w + ((size_t)o * I + cb * CB + ci) * 9;
+                double g[3][3], r[4][3], u[4][4];
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) g[a][b] = (double)eff(wk[a * 3 + b], std, use_std, lr);
+                for (int b = 0; b < 3; ++b) {
+                    r[0][b] = g[0][b];
+                    r[1][b] = 0.5 * ((g[0][b] + g[1][b]) + g[2][b]);
+                    r[2][b] = 0.5 * ((g[0][b] - g[1][b]) + g[2][b]);
+                    r[3][b] = g[2][b];
+                }
+                for (int a = 0; a < 4; ++a) {
+                    u[a][0] = r[a][0];
+                    u[a][1] = 0.5 * ((r[a][0] + r[a][1]) + r[a][2]);
+                    u[a][2] = 0.5 * ((r[a][0] - r[a][1]) + r[a][2]);
+                    u[a][3] = r[a][2];
+                }
+                for (int f = 0; f < 16; ++f) out[(((size_t)cb * 16 + f) * CB + ci) * O + o] = (float)u[f >> 2][f & 3];
+            }
+    return out;
+}
+
 static float* copy_scaled(const float* w, int64_t n, float std, int use_std, float lr) {
     float* out = (float*)malloc(sizeof(float) * (size_t)n);
     for (int64_t i = 0; i < n; ++i) out[i] = eff(w[i], std, use_std, lr);
@@ -261,7 +310,7 @@ static void free_generator(gsao_ctx* c) {
     c->latent_avg = c->psi = c->constant = c->rgb_w = c->rgb_b = NULL;
     for (int l = 0; l < MAX_LEVELS; ++l) {
         gen_block* b = &c->blk[l];
-        free(b->w1); free(b->blur); free(b->w2);
+        free(b->w1); free(b->blur); free(b->w2); free(b->w2u);
         for (int k = 0; k < 2; ++k) { free(b->nscale[k]); free(b->nbias[k]); free(b->aff_w[k]); free(b->aff_b[k]); free(b->gamma[k]); free(b->beta[k]); }
         memset(b, 0, sizeof *b);
     }
@@ -272,7 +321,7 @@ static void free_decoder(gsao_ctx* c) {
     for (int l = 0; l < MAX_LEVELS; ++l) {
         dec_level* d = &c->dl[l];
         float* ptrs[] = {d->cvt_w, d->cvt_b, d->cvt_s, d->cvt_rm, d->cvt_beta, d->a_w, d->a_b, d->a_s, d->a_rm, d->a_beta,
-                         d->b_w, d->b_b, d->b_s, d->b_rm, d->b_beta, d->sc_w, d->sc_b, d->f_w, d->f_b};
+                         d->b_w, d->b_b, d->b_s, d->b_rm, d->b_beta, d->sc_w, d->sc_b, d->f_w, d->f_b, d->cvt_u, d->b_u};
         for (size_t i = 0; i < sizeof ptrs / sizeof *ptrs; ++i) free(ptrs[i]);
         memset(d, 0, sizeof *d);
     }
@@ -408,6 +457,7 @@ GSAO_API int gsao_generator_commit(gsao_ctx* c) {
         { int rc = get_std(c, t, pf, &std); if (rc) return rc; }
         snprintf(nm, sizeof nm, "%s_weight", pf); NEED(t, nm, (int64_t)C * C * 9, &w);
         B->w2 = pack_conv(w, C, C, 3, std, us, 1.0f);
+        B->w2u = pack_wino(w, C, C, std, us, 1.0f);
         for (int k = 0; k < 2; ++k) {
             snprintf(nm, sizeof nm, "%d_noise_%d_scale_factors", R, k + 1); NEED(t, nm, C, &w); B->nscale[k] = copy_plain(w, C);
             snprintf(nm, sizeof nm, "%d_bias_%d_bias", R, k + 1); NEED(t, nm, C, &w); B->nbias[k] = copy_plain(w, C);
@@ -594,6 +644,65 @@ static void deconv4x4s2(const float* in, int Hs, int Ws, int Cin, const float* W
             }
 }
 
+/* 3x3 conv, pad 1, NHWC, Winograd F(2x2,3x3) form (see pack_wino).  in: [H][W][Cin] affine-applied; U packed. */
+static void conv3x3_wino(const float* in, int H, int W, int Cin, const float* U, int Cout, float* out) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int ty = 0; ty < H / 2; ++ty) {
+        float* V = (float*)malloc(sizeof(float) * 16 * (size_t)Cin);       /* [f][c] of the current tile */
+        for (int tx = 0; tx < W / 2; ++tx) {
+            for (int c = 0; c < Cin; ++c) {
+                float d[4][4], t[4][4];
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) {
+                        const int yy = 2 * ty - 1 + i, xx = 2 * tx - 1 + j;
+                        d[i][j] = (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0.0f : in[((size_t)yy * W + xx) * Cin + c];
+                    }
+                for (int j = 0; j < 4; ++j) {
+                    t[0][j] = d[0][j] - d[2][j];
+                    t[1][j] = d[1][j] + d[2][j];
+                    t[2][j] = d[2][j] - d[1][j];
+                    t[3][j] = d[1][j] - d[3][j];
+                }
+                for (int i = 0; i < 4; ++i) {
+                    V[(i * 4 + 0) * Cin + c] = t[i][0] - t[i][2];
+                    V[(i * 4 + 1) * Cin + c] = t[i][1] + t[i][2];
+                    V[(i * 4 + 2) * Cin + c] = t[i][2] - t[i][1];
+                    V[(i * 4 + 3) * Cin + c] = t[i][1] - t[i][3];
+                }
+            }
+            for (int o0 = 0; o0 < Cout; o0 += OC) {
+                const int on = Cout - o0 < OC ? Cout - o0 : OC;
+                float M[16][OC];
+                for (int f = 0; f < 16; ++f) {
+                    float acc[OC];
+                    for (int o = 0; o < OC; ++o) acc[o] = 0.0f;
+                    for (int cb = 0; cb < Cin / CB; ++cb)
+                        for (int ci = 0; ci < CB; ++ci) {
+                            const float a = V[f * Cin + cb * CB + ci];
+                            const float* wrow = U + (((size_t)cb * 16 + f) * CB + ci) * Cout + o0;
+                            for (int o = 0; o < on; ++o) acc[o] = fmaf(a, wrow[o], acc[o]);
+                        }
+                    for (int o = 0; o < OC; ++o) M[f][o] = acc[o];
+                }
+                for (int o = 0; o < on; ++o) {
+                    float sr[2][4];
+                    for (int j = 0; j < 4; ++j) {
+                        sr[0][j] = (M[0 + j][o] + M[4 + j][o]) + M[8 + j][o];
+                        sr[1][j] = (M[4 + j][o] - M[8 + j][o]) - M[12 + j][o];
+                    }
+                    for (int i = 0; i < 2; ++i) {
+                        const float y0 = (sr[i][0] + sr[i][1]) + sr[i][2];
+                        const float y1 = (sr[i][1] - sr[i][2]) - sr[i][3];
+                        out[((size_t)(2 * ty + i) * W + 2 * tx) * Cout + o0 + o] = y0;
+                        out[((size_t)(2 * ty + i) * W + 2 * tx + 1) * Cout + o0 + o] = y1;
+                    }
+                }
+            }
+        }
+        free(V);
+    }
+}
+
 /* depthwise 3x3 blur, zero pad (reference networks_stylegan.py:229-236) */
 static void blur3x3(const float* t, int H, int W, int C, const float* wk /*[C][9]*/, float* out) {
 #pragma omp parallel for schedule(static)
@@ -701,7 +810,8 @@ GSAO_API int gsao_generator_forward(gsao_ctx* c, void* stream, int32_t n, const 
                         blur3x3(xc, R, R, C, B->blur, xa);
                     }
                 } else {
-                    conv3x3(xb, R, R, C, 0, B->w2, C, xa, c->bf16);
+                    if (use_wino(R, R, 0, c->bf16)) conv3x3_wino(xb, R, R, C, B->w2u, C, xa);
+                    else conv3x3(xb, R, R, C, 0, B->w2, C, xa, c->bf16);
                 }
                 noise_bias_act(xa, R, R, C, nz, B->nscale[k], B->nbias[k]);
                 plane_stats(xa, R, R, C, I1, I2);
@@ -791,6 +901,7 @@ GSAO_API int gsao_decoder_commit(gsao_ctx* c) {
         d->F = c->d_feat[i]; d->I = c->d_inch[i];
         snprintf(nm, sizeof nm, "cvt_block_%d.0.weight", i); NEED(t, nm, (int64_t)d->F * d->I * 9, &w);
         d->cvt_w = pack_conv(w, d->F, d->I, 3, 1.0f, 0, 1.0f);
+        d->cvt_u = pack_wino(w, d->F, d->I, 1.0f, 0, 1.0f);
         snprintf(nm, sizeof nm, "cvt_block_%d.0.bias", i); NEED(t, nm, d->F, &b); d->cvt_b = copy_plain(b, d->F);
         snprintf(pf, sizeof pf, "cvt_block_%d.1", i);
         { int rc = load_bn(c, pf, d->F, &d->cvt_s, &d->cvt_rm, &d->cvt_beta); if (rc) return rc; }
@@ -807,6 +918,7 @@ GSAO_API int gsao_decoder_commit(gsao_ctx* c) {
             { int rc = load_bn(c, nm, d->cs, &d->a_s, &d->a_rm, &d->a_beta); if (rc) return rc; }
             snprintf(nm, sizeof nm, "%s.%d.weight", pf, second); NEED(t, nm, (int64_t)d->cs * d->cs * 9, &w);
             d->b_w = pack_conv(w, d->cs, d->cs, 3, 1.0f, 0, 1.0f);
+            d->b_u = pack_wino(w, d->cs, d->cs, 1.0f, 0, 1.0f);
             snprintf(nm, sizeof nm, "%s.%d.bias", pf, second); NEED(t, nm, d->cs, &b); d->b_b = copy_plain(b, d->cs);
             snprintf(nm, sizeof nm, "%s.%d", pf, second + 1);
             { int rc = load_bn(c, nm, d->cs, &d->b_s, &d->b_rm, &d->b_beta); if (rc) return rc; }
@@ -865,7 +977,8 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
             const size_t npix = (size_t)R * R;
             nchw_to_nhwc(feats[i] + (size_t)s * npix * d->I, R, R, d->I, fin);
             /* cvt_block: conv3x3+bias -> BN -> LeakyReLU -> Dropout(identity), reference networks_seg.py:64-79 */
-            conv3x3(fin, R, R, d->I, 0, d->cvt_w, d->F, ya, c->bf16);
+            if (use_wino(R, R, 0, c->bf16)) conv3x3_wino(fin, R, R, d->I, d->cvt_u, d->F, ya);
+            else conv3x3(fin, R, R, d->I, 0, d->cvt_w, d->F, ya, c->bf16);
             bias_bn_act(ya, npix, d->F, d->cvt_b, d->cvt_s, d->cvt_rm, d->cvt_beta);
             /* concat(prev, cvt) on channels, reference :108-109 */
             if (i > c->d_s0) {
@@ -883,7 +996,8 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                 if (R2 >= 16) deconv4x4s2(cat, R, R, d->in_c, d->a_w, d->cs, ya, c->bf16);   /* sub-pixel up+conv */
                 else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya, c->bf16);
                 bias_bn_act(ya, np2, d->cs, d->a_b, d->a_s, d->a_rm, d->a_beta);
-                conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb, c->bf16);
+                if (use_wino(R2, R2, 0, c->bf16)) conv3x3_wino(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
+                else conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb, c->bf16);
                 bias_bn_act(yb, np2, d->cs, d->b_b, d->b_s, d->b_rm, d->b_beta);
 #pragma omp parallel for schedule(static)
                 for (int y = 0; y < R2; ++y)

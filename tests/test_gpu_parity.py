@@ -167,30 +167,6 @@ def test_full_size_bit_exact(torch_cuda, oracle_lib, gan, batch):
     assert 0.001 < mask_o.mean() < 0.999                     # the mask is not degenerate
 
 
-def test_wave_specialised_kernel_bit_exact(torch_cuda, oracle_lib, tmp_path):
-    """The experimental wave-specialised conv kernel (GSA_WS=1, off by default) computes the same
-    bits; run in a child process because the switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r)
-from tests.common import gan_setup
-from gan_segmentation_amd.image_generator import ImageGenerator
-from oracle.binding import Oracle
-gcfg, gp, dcfg, dp, z, noise = gan_setup("ffhq", 1)      # 1024^2: both the synth and the decoder variants run
-gen = ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[0], batch_size=1)
-img, mask = gen.generate_batch(z, noise)
-img_o, mask_o = Oracle(gcfg, gp, dcfg, dp).generate(z, noise)
-assert np.array_equal(img.cpu().numpy(), img_o) and np.array_equal(mask.cpu().numpy(), mask_o)
-print("WS_OK")
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSA_WS="1"), capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0 and "WS_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
-
-
 def test_cli_generate_writes_dataset(torch_cuda, tmp_path):
     """`main.py generate` (reference main.py:75-104): same config.yml keys, img_%06d.jpg (RGB) and
     mask_%06d.png (single channel, class index) under BASE_DIR/dataset/train_generated."""
