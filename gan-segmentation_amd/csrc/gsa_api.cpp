@@ -323,8 +323,9 @@ std::vector<float> pack_wino(const float* w, int O, int I, float std, bool us, f
     return out;
 }
 
-// the static rule of the Winograd form (gsa_kernels.hip conv_uses_wino): plain 3x3 convs with outputs >= 32 px, fp32 mode
-inline bool wino_layer(const gsa_ctx* c, int R) { return !c->bf16 && R >= 32; }
+// the static rule of the Winograd form (gsa_kernels.hip conv_uses_wino): plain 3x3 convs with outputs >= 64 px, or >= 32 px with
+// at least 64 output channels (fewer tiles than that leave the chip idle: the direct small-tile kernels are faster there), fp32 mode
+inline bool wino_layer(const gsa_ctx* c, int R, int Cout) { return !c->bf16 && (R >= 64 || (R >= 32 && Cout >= 64)); }
 
 // final conv (K,I,3,3) -> [cb][tap][c16][K]
 std::vector<float> pack_final(const float* w, int K, int I) {
@@ -629,7 +630,7 @@ int gsa_generator_commit(gsa_ctx* c) {
         h = pack_conv3(w, C, C, std, us, 1.0f);
         if (int rc = upload_mfma(c, h, &B.w2, T)) return rc;
         B.w2u = nullptr;
-        if (wino_layer(c, R)) {
+        if (wino_layer(c, R, C)) {
             h = pack_wino(w, C, C, std, us, 1.0f);
             if (int rc = upload(c, h, &B.w2u, T)) return rc;
         }
@@ -758,7 +759,7 @@ int gsa_decoder_commit(gsa_ctx* c) {
         h = pack_conv3(w, d.F, d.I, 1.0f, false, 1.0f);
         if (int rc = upload_mfma(c, h, &d.cvt_w, T)) return rc;
         d.cvt_u = d.b_u = nullptr;
-        if (wino_layer(c, 4 << i)) {
+        if (wino_layer(c, 4 << i, d.F)) {
             h = pack_wino(w, d.F, d.I, 1.0f, false, 1.0f);
             if (int rc = upload(c, h, &d.cvt_u, T)) return rc;
         }
@@ -780,7 +781,7 @@ int gsa_decoder_commit(gsa_ctx* c) {
             NEED(P, pf + "." + std::to_string(second) + ".bias", (size_t)d.cs, &b);
             h = pack_conv3(w, d.cs, d.cs, 1.0f, false, 1.0f);
             if (int rc = upload_mfma(c, h, &d.b_w, T)) return rc;
-            if (wino_layer(c, 8 << i)) {
+            if (wino_layer(c, 8 << i, d.cs)) {
                 h = pack_wino(w, d.cs, d.cs, 1.0f, false, 1.0f);
                 if (int rc = upload(c, h, &d.b_u, T)) return rc;
             }

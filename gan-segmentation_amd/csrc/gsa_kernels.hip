@@ -777,18 +777,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 // Staging (AdaIN on read, zero padding, double-buffered LDS image, prefetch two items ahead, resident or streamed
 // weight panel, direct statistics, XCD-aware tile walk) is the structure of conv3x3_mfma's double-buffered form.
 // blockIdx.y = output-channel group, so a resident panel never changes under a persistent workgroup.
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvParams p) {
+template <int EPI, int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams p) {
     constexpr int NTHR = 256, LH = 18, LW = 18, RS = LW * 16 + 4;
     constexpr int SEG = 16 * 256;                // U floats per (16 couts, 16-channel block): 16 frequencies x [ci][16][cg]
-    constexpr int NB4 = SEG / 4, BIT = NB4 / NTHR;
+    constexpr int NB4 = SEG / 4, BIT = NT * NB4 / NTHR;      // 16-byte pieces of one (16 couts, block) segment; pieces per thread of a block
     constexpr int AIT = (LH * LW + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nblk = p.C0 >> 4;
     const bool wres = p.w_resident != 0;
     float* sA = smem;                            // [2][LH*RS]
-    float* sB = sA + 2 * LH * RS;                // resident: [nblk][SEG]; streamed: [2][SEG]
-    f32x4* sAff = reinterpret_cast<f32x4*>(sB + (wres ? nblk : 2) * SEG);   // [2][16] (mean, A, B, -)
+    float* sB = sA + 2 * LH * RS;                // resident: [nblk][NT][SEG]; streamed: [2][NT][SEG]
+    f32x4* sAff = reinterpret_cast<f32x4*>(sB + (wres ? nblk : 2) * NT * SEG);   // [2][16] (mean, A, B, -)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -829,19 +829,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvParams p) {
     const int pbase = ((wave >> 1) * 8 + 2 * wty) * RS + ((wave & 1) * 8 + 2 * wtx) * 16 + kq * 4;
     const int bbase = (kq * 16 + i16) * 4;
 
-    f32x4 acc[16];
+    f32x4 acc[16][NT];
 #pragma unroll
-    for (int f = 0; f < 16; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const bool has_aff = p.aff0 != nullptr;
     f32x4 ra[AIT][4], rb[BIT], rf;
-    const float* wgrp = p.wpk + (size_t)g * nblk * SEG;      // U panel of this output-channel group
+    const float* wgrp = p.wpk + (size_t)g * NT * nblk * SEG;      // U panels of this output-channel group: [q][cb][SEG]
+    int wsrc[BIT];                                   // this thread's pieces of a block: q*nblk*SEG + 4r floats
+#pragma unroll
+    for (int j = 0; j < BIT; ++j) {
+        const int i = tid + j * NTHR;
+        wsrc[j] = (i / NB4) * nblk * SEG + (i % NB4) * 4;
+    }
     auto load_item = [&](const Tile& t, int cb, const TilePixel (&tp)[AIT]) {
 #pragma unroll
         for (int it = 0; it < AIT; ++it) load_pixel(ra[it], p.src0, p.C0, cb * 16, tp[it]);
         if (!wres) {
 #pragma unroll
-            for (int j = 0; j < BIT; ++j) rb[j] = reinterpret_cast<const f32x4*>(wgrp + (size_t)cb * SEG)[tid + j * NTHR];
+            for (int j = 0; j < BIT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wgrp + (size_t)cb * SEG + wsrc[j]);
         }
         if (has_aff) rf = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0 + cb * 16)[tid & 15];
     };
@@ -868,7 +876,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvParams p) {
         }
         if (!wres) {
 #pragma unroll
-            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * SEG)[tid + j * NTHR] = rb[j];
+            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * (NT * SEG))[tid + j * NTHR] = rb[j];
         }
     };
 
@@ -876,21 +884,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvParams p) {
     // registers after the output transform: row r of the patch as an x-quad
     const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;     // quad-transposed store layout
     const int prow0 = (wave >> 1) * 8 + ((lane >> 5) & 1) * 4, pcol0 = (wave & 1) * 8 + ((lane >> 4) & 1) * 4;
-    const int co = g * 16 + i16;
-    const unsigned lane_out = (unsigned)((prow0 * p.W + pcol0 + xj) * p.Cout + g * 16 + cq4);
+    const int co0 = g * (16 * NT);                        // first output channel of the group
+    const unsigned lane_out = (unsigned)((prow0 * p.W + pcol0 + xj) * p.Cout + co0 + cq4);
     const unsigned lane_nz = (unsigned)(prow0 * p.W + pcol0);
     const bool has_resid = EPI == EPI_DEC && p.resid != nullptr;
     const int ru = p.resid_up;
     const int res_cs0 = p.resid1 ? p.res_c0 : p.Cout, res_cs1 = p.Cout - p.res_c0;
-    const bool res_second = p.resid1 != nullptr && g * 16 >= p.res_c0;     // a 16-channel group never straddles the split
-    const float* res_src = res_second ? p.resid1 : p.resid;
-    const int res_cs = res_second ? res_cs1 : res_cs0;
-    const int res_ch = res_second ? g * 16 - p.res_c0 : g * 16;
     float4 nzs[EPI == EPI_SYNTH ? 4 : 1];
-    f32x4 rr[EPI == EPI_DEC ? 4 : 1];
-    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
-    if (EPI == EPI_SYNTH) { e0 = p.nscale[co]; e1 = p.nbias[co]; }
-    if (EPI == EPI_DEC) { e0 = p.bias[co]; e1 = p.bn_rm[co]; e2 = p.bn_s[co]; e3 = p.bn_beta[co]; }
+    f32x4 rr[EPI == EPI_DEC ? 4 : 1][EPI == EPI_DEC ? NT : 1];
+    float e0[NT], e1[NT], e2[NT], e3[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = co0 + nt * 16 + i16;
+        e0[nt] = e1[nt] = e2[nt] = e3[nt] = 0.f;
+        if (EPI == EPI_SYNTH) { e0[nt] = p.nscale[co]; e1[nt] = p.nbias[co]; }
+        if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
+    }
     auto epilogue_loads = [&](const Tile& tc) {
         if (EPI == EPI_SYNTH) {
             const float* nz = p.noise + ((size_t)(tc.n * p.H + tc.y0) * p.W + tc.x0) + lane_nz;
@@ -902,79 +911,94 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const size_t rpix = (size_t)(tc.n * (p.H >> ru) + ((tc.y0 + prow0 + r) >> ru)) * Wr + ((tc.x0 + pcol0 + xj) >> ru);
-                rr[r] = *reinterpret_cast<const f32x4*>(res_src + rpix * res_cs + res_ch + cq4);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    // the residual may be concat(resid [res_c0 channels], resid1): a 16-channel group never straddles the split
+                    const int cch = co0 + nt * 16;
+                    const bool second = p.resid1 != nullptr && cch >= p.res_c0;
+                    const float* rsrc = (second ? p.resid1 : p.resid) + rpix * (second ? res_cs1 : res_cs0) + (second ? cch - p.res_c0 : cch);
+                    rr[r][nt] = *reinterpret_cast<const f32x4*>(rsrc + cq4);
+                }
             }
         }
     };
     const bool stats_direct = EPI == EPI_SYNTH && p.stats_direct;
-    unsigned long long dI1 = 0ull, dI2 = 0ull;
+    unsigned long long dI1[NT], dI2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dI1[nt] = dI2[nt] = 0ull;
     auto flush_stats = [&](const Tile& t) {
-        unsigned long long I1 = dI1, I2 = dI2;
-        I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
-        I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
-        if (lane < 16) {
-            StatPart* a = p.partials + ((size_t)t.n * p.prow + (blockIdx.x & (kDirectRows - 1))) * p.Cout + co;
-            atomicAdd(&a->s1, I1);
-            atomicAdd(&a->s2, I2);
-        }
-        dI1 = dI2 = 0ull;
-    };
-    auto epilogue = [&](const Tile& tc) {
-        // output transform Y = A^T M A: rows s0 = (M0+M1)+M2, s1 = (M1-M2)-M3, then the same along the columns;
-        // register component = Winograd tile (b1, b0) of the lane's 4x4 patch
-        f32x4 s0[4], s1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s0[j] = (acc[j] + acc[4 + j]) + acc[8 + j];
-            s1[j] = (acc[4 + j] - acc[8 + j]) - acc[12 + j];
-        }
-        const f32x4 y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];     // tile row 0: x = 0, 1
-        const f32x4 y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];     // tile row 1
-#pragma unroll
-        for (int f = 0; f < 16; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned long long I1 = 0, I2 = 0;
-        const size_t ubase = ((size_t)(tc.n * p.H + tc.y0) * p.W + tc.x0) * p.Cout;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            // patch row r = 2*b1 + i: tiles (b1, 0) and (b1, 1), tile row i
-            const int b1 = r >> 1;
-            const f32x4& ya = (r & 1) ? y10 : y00;
-            const f32x4& yb = (r & 1) ? y11 : y01;
-            float v[4] = {ya[2 * b1], yb[2 * b1], ya[2 * b1 + 1], yb[2 * b1 + 1]};
-            if (EPI == EPI_SYNTH) {
-                const float nzv[4] = {nzs[r].x, nzs[r].y, nzs[r].z, nzs[r].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float t = e0 * nzv[k];
-                    v[k] = lrelu((v[k] + t) + e1);
-                }
-                const float sq = (v[0] + v[1]) + (v[2] + v[3]);
-                const float qq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                I1 += to_fixed(sq, kStatScale1);
-                I2 += to_fixed(qq, kStatScale2);
-            }
-            if (EPI == EPI_DEC) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float yv = v[k] + e0;
-                    v[k] = lrelu(fmaf(yv - e1, e2, e3));
-                }
-            }
-            f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
-            if (EPI == EPI_DEC && has_resid) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) vt[k] = rr[r][k] + vt[k];
-            }
-            *reinterpret_cast<f32x4*>(p.out + ubase + (size_t)r * p.W * p.Cout + lane_out) = vt;
-        }
-        if (EPI == EPI_SYNTH && stats_direct) {
-            dI1 += I1; dI2 += I2;
-        } else if (EPI == EPI_SYNTH) {
+        for (int nt = 0; nt < NT; ++nt) {
+            unsigned long long I1 = dI1[nt], I2 = dI2[nt];
             I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
             I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
             if (lane < 16) {
-                StatPart sp; sp.s1 = I1; sp.s2 = I2;
-                p.partials[((size_t)tc.n * p.prow + tc.row * 4 + wave) * p.Cout + co] = sp;
+                StatPart* a = p.partials + ((size_t)t.n * p.prow + (blockIdx.x & (kDirectRows - 1))) * p.Cout + co0 + nt * 16 + i16;
+                atomicAdd(&a->s1, I1);
+                atomicAdd(&a->s2, I2);
+            }
+            dI1[nt] = dI2[nt] = 0ull;
+        }
+    };
+    auto epilogue = [&](const Tile& tc) {
+        const size_t ubase = ((size_t)(tc.n * p.H + tc.y0) * p.W + tc.x0) * p.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            // output transform Y = A^T M A: rows s0 = (M0+M1)+M2, s1 = (M1-M2)-M3, then the same along the columns;
+            // register component = Winograd tile (b1, b0) of the lane's 4x4 patch
+            f32x4 s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = (acc[j][nt] + acc[4 + j][nt]) + acc[8 + j][nt];
+                s1[j] = (acc[4 + j][nt] - acc[8 + j][nt]) - acc[12 + j][nt];
+            }
+            const f32x4 y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];     // tile row 0: x = 0, 1
+            const f32x4 y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];     // tile row 1
+#pragma unroll
+            for (int f = 0; f < 16; ++f) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            unsigned long long I1 = 0, I2 = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // patch row r = 2*b1 + i: tiles (b1, 0) and (b1, 1), tile row i
+                const int b1 = r >> 1;
+                const f32x4& ya = (r & 1) ? y10 : y00;
+                const f32x4& yb = (r & 1) ? y11 : y01;
+                float v[4] = {ya[2 * b1], yb[2 * b1], ya[2 * b1 + 1], yb[2 * b1 + 1]};
+                if (EPI == EPI_SYNTH) {
+                    const float nzv[4] = {nzs[r].x, nzs[r].y, nzs[r].z, nzs[r].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float t = e0[nt] * nzv[k];
+                        v[k] = lrelu((v[k] + t) + e1[nt]);
+                    }
+                    const float sq = (v[0] + v[1]) + (v[2] + v[3]);
+                    const float qq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    I1 += to_fixed(sq, kStatScale1);
+                    I2 += to_fixed(qq, kStatScale2);
+                }
+                if (EPI == EPI_DEC) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float yv = v[k] + e0[nt];
+                        v[k] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
+                    }
+                }
+                f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
+                if (EPI == EPI_DEC && has_resid) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) vt[k] = rr[r][nt][k] + vt[k];
+                }
+                *reinterpret_cast<f32x4*>(p.out + ubase + (size_t)r * p.W * p.Cout + nt * 16 + lane_out) = vt;
+            }
+            if (EPI == EPI_SYNTH && stats_direct) {
+                dI1[nt] += I1; dI2[nt] += I2;
+            } else if (EPI == EPI_SYNTH) {
+                I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
+                I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
+                if (lane < 16) {
+                    StatPart sp; sp.s1 = I1; sp.s2 = I2;
+                    p.partials[((size_t)tc.n * p.prow + tc.row * 4 + wave) * p.Cout + co0 + nt * 16 + i16] = sp;
+                }
             }
         }
     };
@@ -982,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvParams p) {
     auto wino_item = [&](int buf, int cb_res) {
         __builtin_amdgcn_s_setprio(GSA_MFMA_PRIO);
         const float* a_img = sA + buf * (LH * RS) + pbase;
-        const float* b_img = sB + (wres ? cb_res : buf) * SEG + bbase;
+        const float* b_img = sB + (wres ? cb_res : buf) * (NT * SEG) + bbase;
         // input transform V = B^T d B on the lane's 4x4 patch, four channels (cg) per vector:
         //   rows  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3;   columns: the same four forms
         f32x4 V[16];
@@ -1008,14 +1032,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvParams p) {
         // sixteen GEMMs: per frequency one chain over the block's channels (cg ascending), four frequencies interleaved
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
-            f32x4 b[4];
+            f32x4 b[4][NT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_img + (fb * 4 + j) * 256);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[j][nt] = *reinterpret_cast<const f32x4*>(b_img + nt * SEG + (fb * 4 + j) * 256);
 #pragma unroll
             for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[fb * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[fb * 4 + j][cg], b[j][cg], acc[fb * 4 + j], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[fb * 4 + j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[fb * 4 + j][cg], b[j][nt][cg], acc[fb * 4 + j][nt], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -1038,9 +1066,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvParams p) {
     if (wres) {
         for (int cbk = 0; cbk < nblk; ++cbk) {
 #pragma unroll
-            for (int j = 0; j < BIT; ++j) rb[j] = reinterpret_cast<const f32x4*>(wgrp + (size_t)cbk * SEG)[tid + j * NTHR];
+            for (int j = 0; j < BIT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wgrp + (size_t)cbk * SEG + wsrc[j]);
 #pragma unroll
-            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + cbk * SEG)[tid + j * NTHR] = rb[j];
+            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + cbk * (NT * SEG))[tid + j * NTHR] = rb[j];
         }
     }
     load_item(tc, cb, tpr);
@@ -2307,16 +2335,24 @@ static hipError_t launch_conv_e(const ConvParams& p, int epi, bool sc, int n, hi
 bool conv_uses_wino(const ConvParams& p, int epi, bool sc) {
     static const bool enabled = !(getenv("GSA_WINO") && atoi(getenv("GSA_WINO")) == 0);
     return enabled && p.wino != nullptr && !p.bf16 && !sc && !p.up && p.src1 == nullptr && p.C1 == 0 && epi != EPI_RAW &&
-           p.H >= 32 && p.W >= 32 && p.H % 16 == 0 && p.W % 16 == 0 && p.Cout % 16 == 0 && p.C0 % 16 == 0;
+           (p.H >= 64 || (p.H >= 32 && p.Cout >= 64)) && p.H == p.W && p.H % 16 == 0 && p.Cout % 16 == 0 && p.C0 % 16 == 0;
 }
 
-template <int EPI>
+// output channels per workgroup = 16*NT.  NT = 2 (one workgroup per CU with the whole register file, the input transform and
+// the staging shared by 32 output channels) measured SLOWER than two NT = 1 workgroups per CU (g.512.conv_2: 0.35 vs 0.30 ms):
+// a lone wave per SIMD does not hide its own LDS / MFMA latencies.  Kept for A/B runs (GSA_WINO_NT=2); speed only, same bits.
+static int wino_nt(const ConvParams& p) {
+    static const int forced = getenv("GSA_WINO_NT") ? atoi(getenv("GSA_WINO_NT")) : 1;
+    return (forced >= 2 && p.Cout % 32 == 0) ? 2 : 1;
+}
+
+template <int EPI, int NT>
 static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int RS = 18 * 16 + 4, SEG = 16 * 256;
     const int nblk = p.C0 / 16;
-    const bool wres = (size_t)nblk * SEG * sizeof(float) <= 36 * 1024;      // whole panel of the group resident (<= 32 input channels)
-    const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * SEG) + 32 * sizeof(float4);
-    auto kern = conv3x3_wino<EPI>;
+    const bool wres = (size_t)nblk * NT * SEG * sizeof(float) <= (NT == 1 ? 36 : 72) * 1024;      // whole panel of the group resident (<= 32 input channels)
+    const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * NT * SEG) + 32 * sizeof(float4);
+    auto kern = conv3x3_wino<EPI, NT>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
     int num_cus = 0, wgs_per_cu = 0;
@@ -2334,7 +2370,7 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
             if (e != hipSuccess) return e;
             wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
             if (st.occ_n < 8) { st.occ_lds[st.occ_n] = lds; st.occ_k[st.occ_n] = wgs_per_cu; ++st.occ_n; }
-            if (getenv("GSA_VERBOSE")) fprintf(stderr, "gsa: conv3x3_wino<%d> lds %zu B%s -> %d workgroups/CU\n", EPI, lds, wres ? " (resident weights)" : "", k);
+            if (getenv("GSA_VERBOSE")) fprintf(stderr, "gsa: conv3x3_wino<%d,%d> lds %zu B%s -> %d workgroups/CU\n", EPI, NT, lds, wres ? " (resident weights)" : "", k);
         }
     }
     ConvParams q = p;
@@ -2342,7 +2378,7 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     q.w_resident = wres ? 1 : 0;
     q.tiles_x = p.W / 16;
     q.tiles_y = p.H / 16;
-    q.groups = p.Cout / 16;
+    q.groups = p.Cout / (16 * NT);
     q.prow = q.tiles_x * q.tiles_y * 4;
     q.total_tiles = q.tiles_x * q.tiles_y * n;         // per output-channel group
     // persistent workgroups for short tiles (<= 2 channel blocks); a workgroup stays inside its channel group
@@ -2361,11 +2397,17 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
+static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s) {
+    const int nt = wino_nt(p);
+    if (epi == EPI_SYNTH) return nt == 2 ? launch_wino_t<EPI_SYNTH, 2>(p, n, s) : launch_wino_t<EPI_SYNTH, 1>(p, n, s);
+    return nt == 2 ? launch_wino_t<EPI_DEC, 2>(p, n, s) : launch_wino_t<EPI_DEC, 1>(p, n, s);
+}
+
 // exact C++ name of the instantiation launch_conv3x3 picks (profile labels spell kernels as rocprofv3 prints them)
 const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     static thread_local char buf[128];
     if (conv_uses_wino(p, epi, sc)) {
-        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d>(gsa::ConvParams)", epi);
+        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d, %d>(gsa::ConvParams)", epi, wino_nt(p));
         return buf;
     }
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
@@ -2376,7 +2418,7 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
 
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     if (p.H != p.W || (p.H & (p.H - 1)) || p.H < 4 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
-    if (conv_uses_wino(p, epi, sc)) return epi == EPI_SYNTH ? launch_wino_t<EPI_SYNTH>(p, n, s) : launch_wino_t<EPI_DEC>(p, n, s);
+    if (conv_uses_wino(p, epi, sc)) return launch_wino(p, epi, n, s);
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
 #define GSA_GEOM(TH, WM, WN, NT) \
     if (c.th == TH && c.wm == WM && c.wn == WN && c.nt == NT) return launch_conv_e<TH, TH, WM, WN, NT>(p, epi, sc, n, s);

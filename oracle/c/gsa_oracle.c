@@ -238,7 +238,7 @@ static float* pack_upconv(const float* w, int O, int I, float std, int use_std, 
 
 /* ---- Winograd F(2x2, 3x3) form of the plain 3x3 convolutions (Lavin & Gray 2016) -------------------------------
  * Rule (static, by layer shape only -- never by batch size): a 3x3 stride-1 convolution WITHOUT upsample-on-read
- * whose output is >= 32 px on a side is evaluated, in fp32 mode, as
+ * whose output is >= 64 px on a side (or >= 32 px with at least 64 output channels) is evaluated, in fp32 mode, as
  *     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A          per 2x2 output tile, 16 products per (tile, c, o)
  * instead of 36: 2.25x fewer multiplications.  Canonical arithmetic (every fp32 op rounded, nothing contracted):
  *   weights    U = G g G^T evaluated in DOUBLE on the effective fp32 weights, rounded to fp32 once;
@@ -250,9 +250,9 @@ static float* pack_upconv(const float* w, int O, int I, float std, int use_std, 
  * The result differs from the 9-tap chain by a few fp32 ulps of the intermediate magnitudes; oracle/ref_semantic.py
  * keeps the reference's 9-tap order and bounds the difference (tests: <= 1e-3 on rgb and logits at full size). */
 static int g_wino_enabled = -1;
-static int use_wino(int H, int W, int up, int bf) {
+static int use_wino(int H, int W, int Cout, int up, int bf) {
     if (g_wino_enabled < 0) { const char* e = getenv("GSAO_WINO"); g_wino_enabled = !(e && atoi(e) == 0); }
-    return g_wino_enabled && !bf && !up && H >= 32 && W >= 32 && H % 16 == 0 && W % 16 == 0;
+    return g_wino_enabled && !bf && !up && H == W && (H >= 64 || (H >= 32 && Cout >= 64)) && H % 16 == 0;
 }
 
 /* conv OIHW (O,I,3,3) -> U packed [(cb*16 + f)*CB + c][O], f = 4*i + j */
@@ -810,7 +810,7 @@ GSAO_API int gsao_generator_forward(gsao_ctx* c, void* stream, int32_t n, const 
                         blur3x3(xc, R, R, C, B->blur, xa);
                     }
                 } else {
-                    if (use_wino(R, R, 0, c->bf16)) conv3x3_wino(xb, R, R, C, B->w2u, C, xa);
+                    if (use_wino(R, R, C, 0, c->bf16)) conv3x3_wino(xb, R, R, C, B->w2u, C, xa);
                     else conv3x3(xb, R, R, C, 0, B->w2, C, xa, c->bf16);
                 }
                 noise_bias_act(xa, R, R, C, nz, B->nscale[k], B->nbias[k]);
@@ -977,7 +977,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
             const size_t npix = (size_t)R * R;
             nchw_to_nhwc(feats[i] + (size_t)s * npix * d->I, R, R, d->I, fin);
             /* cvt_block: conv3x3+bias -> BN -> LeakyReLU -> Dropout(identity), reference networks_seg.py:64-79 */
-            if (use_wino(R, R, 0, c->bf16)) conv3x3_wino(fin, R, R, d->I, d->cvt_u, d->F, ya);
+            if (use_wino(R, R, d->F, 0, c->bf16)) conv3x3_wino(fin, R, R, d->I, d->cvt_u, d->F, ya);
             else conv3x3(fin, R, R, d->I, 0, d->cvt_w, d->F, ya, c->bf16);
             bias_bn_act(ya, npix, d->F, d->cvt_b, d->cvt_s, d->cvt_rm, d->cvt_beta);
             /* concat(prev, cvt) on channels, reference :108-109 */
@@ -996,7 +996,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                 if (R2 >= 16) deconv4x4s2(cat, R, R, d->in_c, d->a_w, d->cs, ya, c->bf16);   /* sub-pixel up+conv */
                 else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya, c->bf16);
                 bias_bn_act(ya, np2, d->cs, d->a_b, d->a_s, d->a_rm, d->a_beta);
-                if (use_wino(R2, R2, 0, c->bf16)) conv3x3_wino(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
+                if (use_wino(R2, R2, d->cs, 0, c->bf16)) conv3x3_wino(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
                 else conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb, c->bf16);
                 bias_bn_act(yb, np2, d->cs, d->b_b, d->b_s, d->b_rm, d->b_beta);
 #pragma omp parallel for schedule(static)
