@@ -185,11 +185,7 @@ int upload_mfma(gsa_ctx* c, const std::vector<float>& h, float** out, std::vecto
     if (!c->bf16) return upload(c, h, out, track);
     std::vector<float> packed(h.size() / 2);
     uint16_t* o = reinterpret_cast<uint16_t*>(packed.data());
-    for (size_t chunk = 0; chunk < h.size() / 256; ++chunk)
-        for (int ci = 0; ci < 4; ++ci)
-            for (int n = 0; n < 16; ++n)
-                for (int cg = 0; cg < 4; ++cg)
-                    o[chunk * 256 + (cg * 16 + n) * 4 + ci] = bf16_rne(h[chunk * 256 + (ci * 16 + n) * 4 + cg]);
+    for (size_t i = 0; i < h.size(); ++i) o[i] = bf16_rne(h[i]);      // [kq][16][j], channel 4kq+j: the fp32 pack order already
     return upload(c, packed, out, track);
 }
 
@@ -207,7 +203,8 @@ void free_all(std::vector<void*>& v) {
     v.clear();
 }
 
-// conv OIHW (O,I,3,3) -> [O/16][I/16][tap][ci][16][cg]; channel = 16cb+4cg+ci, cout = 16g+n
+// conv OIHW (O,I,3,3) -> [O/16][I/16][tap][ci][16][cg]; channel = 16cb+4ci+cg (ci = k slot of the MFMA, cg = which of the
+// four MFMAs of the (tap, block)), cout = 16g+n
 std::vector<float> pack_conv3(const float* w, int O, int I, float std, bool us, float lr) {
     const int ct = 16;
     std::vector<float> out((size_t)O * I * 9);
@@ -218,7 +215,7 @@ std::vector<float> pack_conv3(const float* w, int O, int I, float std, bool us, 
                 for (int ci = 0; ci < 4; ++ci)
                     for (int n = 0; n < ct; ++n)
                         for (int cg = 0; cg < 4; ++cg) {
-                            const int o = g * ct + n, ch = cb * 16 + cg * 4 + ci;
+                            const int o = g * ct + n, ch = cb * 16 + ci * 4 + cg;
                             out[((((((size_t)g * nblk + cb) * 9 + t) * 4 + ci) * ct + n) * 4) + cg] =
                                 eff(w[((size_t)o * I + ch) * 9 + t], std, us, lr);
                         }
@@ -236,7 +233,7 @@ std::vector<float> pack_deconv(const float* w, int I, int O, float std, bool us,
                 for (int ci = 0; ci < 4; ++ci)
                     for (int n = 0; n < ct; ++n)
                         for (int cg = 0; cg < 4; ++cg) {
-                            const int o = g * ct + n, ch = cb * 16 + cg * 4 + ci;
+                            const int o = g * ct + n, ch = cb * 16 + ci * 4 + cg;
                             out[((((((size_t)g * nblk + cb) * 16 + t) * 4 + ci) * ct + n) * 4) + cg] =
                                 eff(w[((size_t)ch * O + o) * 16 + t], std, us, lr);
                         }
@@ -258,7 +255,7 @@ std::vector<float> pack_upconv(const float* w, int O, int I, float std, bool us,
                     for (int ci = 0; ci < 4; ++ci)
                         for (int n = 0; n < 16; ++n)
                             for (int cg = 0; cg < 4; ++cg) {
-                                const int o = g * 16 + n, ch = cb * 16 + cg * 4 + ci;
+                                const int o = g * 16 + n, ch = cb * 16 + ci * 4 + cg;
                                 const float* wk = w + ((size_t)o * I + ch) * 9;
                                 float sum = 0.0f;
                                 bool first = true;
@@ -285,7 +282,7 @@ std::vector<float> pack_conv1(const float* w, int O, int I) {
                 for (int n = 0; n < ct; ++n)
                     for (int cg = 0; cg < 4; ++cg)
                         out[(((((size_t)g * nblk + cb) * 4 + ci) * ct + n) * 4) + cg] =
-                            w[(size_t)(g * ct + n) * I + cb * 16 + cg * 4 + ci];
+                            w[(size_t)(g * ct + n) * I + cb * 16 + ci * 4 + cg];
     return out;
 }
 
@@ -300,7 +297,7 @@ std::vector<float> pack_wino(const float* w, int O, int I, float std, bool us, f
             for (int ci = 0; ci < 4; ++ci)
                 for (int n = 0; n < 16; ++n)
                     for (int cg = 0; cg < 4; ++cg) {
-                        const int o = g * 16 + n, ch = cb * 16 + cg * 4 + ci;
+                        const int o = g * 16 + n, ch = cb * 16 + ci * 4 + cg;
                         const float* wk = w + ((size_t)o * I + ch) * 9;
                         double k[3][3], r[4][3], u[4][4];
                         for (int a = 0; a < 3; ++a)

@@ -111,11 +111,12 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // ------------------------------------------------------------------------------------------
 // Shared pieces of the two MFMA convolutions.
 //
-// LDS image of an input tile (1-pixel halo): [row][pixel][16 channels]; the 16 channels of a
-// block are stored transposed 4x4 (position ci*4+cg holds channel 4*cg+ci) so ONE ds_read_b128
-// per lane yields the A operands of 4 consecutive MFMAs (lane = (pixel i, k slot ci)).  A row
-// stride = 8 (mod 16) floats makes those reads bank-conflict free.  Weights are packed in HBM
-// per (16 output channels, 16-channel block) as [tap][ci][n][cg] and copied verbatim.
+// LDS image of an input tile (1-pixel halo): [row][pixel][16 channels] in natural channel order.  ONE ds_read_b128
+// per lane (pixel i, k slot kq) at chunk kq yields channels 4kq..4kq+3 = the A operands of 4 consecutive MFMAs:
+// MFMA j of a (tap, block) multiplies the channels {j, 4+j, 8+j, 12+j} (k slot kq <-> channel 4kq+j), so the
+// canonical order of a 16-channel block is 0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15 (the oracle walks the
+// same order).  A row stride = 8 (mod 16) floats makes those reads bank-conflict free.  Weights are packed in HBM
+// per (16 output channels, 16-channel block) as [tap][kq][n][j] (channel 4kq+j) and copied verbatim.
 //
 // Staging is split (load to registers early / write to LDS late) so that the global loads of
 // block cb+1 are in flight while the MFMAs of block cb run.
@@ -167,12 +168,12 @@ __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const floa
         }
         return;
     }
-    if (tp.lds >= 0) {
+    if (tp.lds >= 0) {      // natural channel order: the 16-byte chunk kq holds channels 4kq..4kq+3
         f32x4* dst = reinterpret_cast<f32x4*>(sA + tp.lds);
-        dst[0] = f32x4{f[0], f[4], f[8], f[12]};
-        dst[1] = f32x4{f[1], f[5], f[9], f[13]};
-        dst[2] = f32x4{f[2], f[6], f[10], f[14]};
-        dst[3] = f32x4{f[3], f[7], f[11], f[15]};
+        dst[0] = f32x4{f[0], f[1], f[2], f[3]};
+        dst[1] = f32x4{f[4], f[5], f[6], f[7]};
+        dst[2] = f32x4{f[8], f[9], f[10], f[11]};
+        dst[3] = f32x4{f[12], f[13], f[14], f[15]};
     }
 }
 

@@ -26,7 +26,7 @@
  *
  * Canonical arithmetic (all fp32 round-to-nearest, no contraction except explicit fmaf):
  *   up+conv (nearest x2 then 3x3, outputs >= 16 px): sub-pixel form, see pack_upconv()
- *   conv   acc=0; for cb in Cin/16: for ky: for kx: for c in 16: acc=fmaf(in[16cb+c],w,acc)
+ *   conv   acc=0; for cb in Cin/16: for ky: for kx: for c in (0,4,8,12,1,5,9,13,2,6,10,14,3,7,11,15): acc=fmaf(in[16cb+c],w,acc)
  *          (channels in blocks of 16, the taps inside a block; out-of-image taps skipped,
  *          which equals adding +0; 1x1 convs and dense layers are plain k-ordered chains)
  *   stats  per (n,c), per aligned quad of 4 consecutive x:
@@ -182,6 +182,10 @@ static inline float eff(float w, float std, int use_std, float lr) {
 
 /* conv OIHW (O,I,K,K) -> packed [(cb*K*K + tap)*CB + c][O]; I % CB == 0 */
 #define CB 16
+/* canonical order of the 16 channels of a block inside the MFMA convolutions: 0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15
+ * (MFMA j of a (tap, block) multiplies the channels {j, 4+j, 8+j, 12+j}: k slot kq <-> channel 4kq+j, the natural
+ * 16-byte chunks of the NHWC tensors) */
+#define CPERM(k) ((((k) & 3) << 2) | ((k) >> 2))
 static float* pack_conv(const float* w, int O, int I, int K, float std, int use_std, float lr) {
     float* out = (float*)malloc(sizeof(float) * (size_t)O * I * K * K);
     for (int cb = 0; cb < I / CB; ++cb)
@@ -244,7 +248,7 @@ static float* pack_upconv(const float* w, int O, int I, float std, int use_std, 
  *   weights    U = G g G^T evaluated in DOUBLE on the effective fp32 weights, rounded to fp32 once;
  *   input      t = B^T d (rows), V = t B (columns):  t0=d0-d2, t1=d1+d2, t2=d2-d1, t3=d1-d3  (d = AdaIN-applied,
  *              zero outside the image), the same four forms along the columns;
- *   products   M[f] = fmaf chain over the input channels ascending (16-channel blocks, as everywhere), per
+ *   products   M[f] = fmaf chain over the input channels (16-channel blocks ascending, CPERM order inside), per
  *              frequency f = 4i+j separately -- bitwise what v_mfma_f32_16x16x4_f32 produces;
  *   output     s0=(M0+M1)+M2, s1=(M1-M2)-M3 along the rows, the same two forms along the columns.
  * The result differs from the 9-tap chain by a few fp32 ulps of the intermediate magnitudes; oracle/ref_semantic.py
@@ -577,7 +581,7 @@ static inline float bf16r(float f) {
 /* 3x3 conv, pad 1, NHWC.  in: [Hs][Ws][Cin] (already affine-applied); when up!=0 the
  * logical input is the nearest-x2 upsample of `in` (UpSampling, reference :308-315).
  * out: raw accumulators [H][W][Cout], H = Hs<<up. */
-static void conv3x3(const float* in, int Hs, int Ws, int Cin, int up, const float* Wp, int Cout, float* out, int bf) {
+static void conv3x3(const float* in, int Hs, int Ws, int Cin, int up, const float* Wp, int Cout, float* out, int bf, int perm) {
     const int H = Hs << up, W = Ws << up;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int y = 0; y < H; ++y)
@@ -592,7 +596,8 @@ static void conv3x3(const float* in, int Hs, int Ws, int Cin, int up, const floa
                         const int yy = y + ky - 1;
                         if (yy < 0 || yy >= H) continue;
                         for (int kx = 0; kx < 3; ++kx)
-                            for (int ci = 0; ci < CB; ++ci) {
+                            for (int kk = 0; kk < CB; ++kk) {
+                                const int ci = perm ? CPERM(kk) : kk;     /* perm = 0: the final conv (vector ALU, ascending channels) */
                                 const float* wsrc = Wp + (((size_t)cb * 9 + ky * 3 + kx) * CB + ci) * Cout + o0;
                                 float wrow[OC];
                                 for (int o = 0; o < on; ++o) wrow[o] = OPND(wsrc[o]);
@@ -633,7 +638,8 @@ static void deconv4x4s2(const float* in, int Hs, int Ws, int Cin, const float* W
                         for (int kx = (ox + 1) & 1; kx < 4; kx += 2) {
                             const int ix = (ox + 1 - kx) / 2;
                             if (ox + 1 - kx < 0 || ix >= Ws) continue;
-                            for (int ci = 0; ci < CB; ++ci) {
+                            for (int kk = 0; kk < CB; ++kk) {
+                                const int ci = CPERM(kk);
                                 const float a = OPND(in[((size_t)iy * Ws + ix) * Cin + cb * CB + ci]);
                                 const float* wrow = Wd + (((size_t)cb * 16 + ky * 4 + kx) * CB + ci) * Cout + o0;
                                 for (int o = 0; o < on; ++o) acc[o] = fmaf(a, OPND(wrow[o]), acc[o]);
@@ -677,7 +683,8 @@ static void conv3x3_wino(const float* in, int H, int W, int Cin, const float* U,
                     float acc[OC];
                     for (int o = 0; o < OC; ++o) acc[o] = 0.0f;
                     for (int cb = 0; cb < Cin / CB; ++cb)
-                        for (int ci = 0; ci < CB; ++ci) {
+                        for (int kk = 0; kk < CB; ++kk) {
+                            const int ci = CPERM(kk);
                             const float a = V[f * Cin + cb * CB + ci];
                             const float* wrow = U + (((size_t)cb * 16 + f) * CB + ci) * Cout + o0;
                             for (int o = 0; o < on; ++o) acc[o] = fmaf(a, wrow[o], acc[o]);
@@ -806,12 +813,12 @@ GSAO_API int gsao_generator_forward(gsao_ctx* c, void* stream, int32_t n, const 
                         /* xb holds the affine-applied previous feature */
                         if (B->is_deconv) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc, c->bf16);
                         else if (R >= 16) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc, c->bf16);   /* sub-pixel up+conv */
-                        else conv3x3(xb, R / 2, R / 2, Cin, 1, B->w1, C, xc, c->bf16);
+                        else conv3x3(xb, R / 2, R / 2, Cin, 1, B->w1, C, xc, c->bf16, 1);
                         blur3x3(xc, R, R, C, B->blur, xa);
                     }
                 } else {
                     if (use_wino(R, R, C, 0, c->bf16)) conv3x3_wino(xb, R, R, C, B->w2u, C, xa);
-                    else conv3x3(xb, R, R, C, 0, B->w2, C, xa, c->bf16);
+                    else conv3x3(xb, R, R, C, 0, B->w2, C, xa, c->bf16, 1);
                 }
                 noise_bias_act(xa, R, R, C, nz, B->nscale[k], B->nbias[k]);
                 plane_stats(xa, R, R, C, I1, I2);
@@ -978,7 +985,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
             nchw_to_nhwc(feats[i] + (size_t)s * npix * d->I, R, R, d->I, fin);
             /* cvt_block: conv3x3+bias -> BN -> LeakyReLU -> Dropout(identity), reference networks_seg.py:64-79 */
             if (use_wino(R, R, d->F, 0, c->bf16)) conv3x3_wino(fin, R, R, d->I, d->cvt_u, d->F, ya);
-            else conv3x3(fin, R, R, d->I, 0, d->cvt_w, d->F, ya, c->bf16);
+            else conv3x3(fin, R, R, d->I, 0, d->cvt_w, d->F, ya, c->bf16, 1);
             bias_bn_act(ya, npix, d->F, d->cvt_b, d->cvt_s, d->cvt_rm, d->cvt_beta);
             /* concat(prev, cvt) on channels, reference :108-109 */
             if (i > c->d_s0) {
@@ -994,10 +1001,10 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                 const int R2 = 2 * R;
                 const size_t np2 = (size_t)R2 * R2;
                 if (R2 >= 16) deconv4x4s2(cat, R, R, d->in_c, d->a_w, d->cs, ya, c->bf16);   /* sub-pixel up+conv */
-                else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya, c->bf16);
+                else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya, c->bf16, 1);
                 bias_bn_act(ya, np2, d->cs, d->a_b, d->a_s, d->a_rm, d->a_beta);
                 if (use_wino(R2, R2, d->cs, 0, c->bf16)) conv3x3_wino(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
-                else conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb, c->bf16);
+                else conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb, c->bf16, 1);
                 bias_bn_act(yb, np2, d->cs, d->b_b, d->b_s, d->b_rm, d->b_beta);
 #pragma omp parallel for schedule(static)
                 for (int y = 0; y < R2; ++y)
@@ -1010,7 +1017,10 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                             if (d->has_sc) {
                                 float acc = 0.0f;
                                 const int bf = c->bf16;
-                                for (int ch = 0; ch < d->in_c; ++ch) acc = fmaf(OPND(src[ch]), OPND(d->sc_w[(size_t)ch * d->cs + o]), acc);
+                                for (int k0 = 0; k0 < d->in_c; ++k0) {      /* the MFMA order of the 16-channel blocks */
+                                    const int ch = (k0 & ~15) | CPERM(k0 & 15);
+                                    acc = fmaf(OPND(src[ch]), OPND(d->sc_w[(size_t)ch * d->cs + o]), acc);
+                                }
                                 sc = acc + d->sc_b[o];
                             } else {
                                 sc = src[o];
@@ -1021,7 +1031,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
             } else {
                 /* final conv3x3 + bias -> logits, then argmax (first maximum), reference :91-92, seg_solver.py:326 */
                 const int nc = d->cs;
-                conv3x3(cat, R, R, d->in_c, 0, d->f_w, nc, ya, 0);   /* final conv: fp32 in both modes */
+                conv3x3(cat, R, R, d->in_c, 0, d->f_w, nc, ya, 0, 0);   /* final conv: fp32 in both modes, ascending channel order */
                 for (size_t p = 0; p < npix; ++p) {
                     int best = 0;
                     float bv = 0.0f;
