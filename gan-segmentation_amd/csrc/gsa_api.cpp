@@ -927,7 +927,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 snprintf(layer, sizeof layer, "g.%d.post_1", R);
                 Launch lp(c, s, pp.blur ? "post_kernel<blur>" : "post_kernel<const>", layer, 0.0, 4.0 * (2 * px * C + px));
                 HIP_TRY(launch_post(pp, n, s));
-                prow = post_prow(R, R, C);
+                prow = post_rows_used(pp);
             } else {
                 ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
                 cp.src0 = c->x1; cp.aff0 = c->aff1; cp.C0 = C;

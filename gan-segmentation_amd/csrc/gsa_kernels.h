@@ -89,7 +89,8 @@ hipError_t launch_final_conv(const float* src0, int C0, const float* src1, int C
 
 // geometry the launchers pick (weights are packed per 16 output channels, so it is free to vary)
 int conv_stat_rows(int H, int W, int Cout, int n);   // statistic partial rows per sample written by conv3x3 EPI_SYNTH
-int post_prow(int H, int W, int C);                  // ... written by the post kernel
+int post_prow(int H, int W, int C);                  // ... written by the post kernel (upper bound: the one-row form)
+int post_rows_used(const PostParams& p);             // ... by the form launch_post picks for p
 const char* subpixel_kernel_name(const ConvParams& p, int epi, bool sc, int n);
 hipError_t launch_fill_normal(float* out, int per_sample, int n, unsigned long long first_index, unsigned plane,
                               unsigned long long seed, hipStream_t s);

@@ -177,6 +177,49 @@ __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const floa
     }
 }
 
+// ---- staging by 16-byte chunks --------------------------------------------------------------------------
+// One chunk = 4 consecutive channels (part*4..+3 of the item's 16-channel block) of one tile pixel: ONE global load,
+// 8 vector-ALU instructions of AdaIN, ONE LDS store.  Thread t of a workgroup stages the chunks q = t + k*NTHR
+// (pixel q >> 2, part q & 3 = t & 3 since NTHR % 4 == 0): a tile of P pixels costs ceil(4P / NTHR) rounds instead of
+// ceil(P / NTHR) rounds of four loads / stores each with most threads idle in the last one (324 pixels on 256 threads:
+// 6 chunk rounds instead of 8; 100 pixels: 2 instead of 4).  A thread's four channels never change, so its AdaIN
+// coefficients are four registers loaded with the item (64 contiguous bytes of Aff) -- no LDS table, no table barrier.
+struct Chunk {
+    int pix;         // pixel index into the source tensor ((n*Hs+sy)*Ws+sx), or -1: zero padding
+    int lds;         // 4-byte slot offset of the chunk in the LDS image, or -1: this thread stages nothing
+};
+
+__device__ __forceinline__ f32x4 load_chunk(const float* src, int Cs, int coff, const Chunk& ch) {
+    const int pix = ch.pix >= 0 ? ch.pix : 0;      // unconditional load (padding reads pixel 0 and discards it)
+    return *reinterpret_cast<const f32x4*>(src + (size_t)pix * Cs + coff);
+}
+
+// the four Aff entries (mean, A, B, -) of channels c0..c0+3 of sample n
+__device__ __forceinline__ void load_aff4(f32x4 (&aff)[4], const Aff* table, size_t first) {
+    const f32x4* ptr = reinterpret_cast<const f32x4*>(table + first);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) aff[c] = ptr[c];
+}
+
+template <bool HAS_AFF, bool BF, bool MASK>
+__device__ __forceinline__ void store_chunk(float* sA, const f32x4& v, const f32x4 (&aff)[4], const Chunk& ch) {
+    const bool inside = !MASK || ch.pix >= 0;
+    float f[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float t = f[c];
+        if (HAS_AFF) t = fmaf(t - aff[c][0], aff[c][1], aff[c][2]);
+        f[c] = inside ? t : 0.0f;
+    }
+    if (ch.lds < 0) return;
+    if (BF) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(sA + ch.lds) = u32x2{pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3])};
+    } else {
+        *reinterpret_cast<f32x4*>(sA + ch.lds) = f32x4{f[0], f[1], f[2], f[3]};
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // conv3x3 (pad 1) as implicit GEMM on v_mfma_f32_16x16x4_f32.
 //
@@ -783,13 +826,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
     constexpr int NTHR = 256, LH = 18, LW = 18, RS = LW * 16 + 4;
     constexpr int SEG = 16 * 256;                // U floats per (16 couts, 16-channel block): 16 frequencies x [ci][16][cg]
     constexpr int NB4 = SEG / 4, BIT = NT * NB4 / NTHR;      // 16-byte pieces of one (16 couts, block) segment; pieces per thread of a block
-    constexpr int AIT = (LH * LW + NTHR - 1) / NTHR;
+    constexpr int NCH = (LH * LW * 4 + NTHR - 1) / NTHR;     // 16-byte chunk rounds per item
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nblk = p.C0 >> 4;
     const bool wres = p.w_resident != 0;
     float* sA = smem;                            // [2][LH*RS]
     float* sB = sA + 2 * LH * RS;                // resident: [nblk][NT][SEG]; streamed: [2][NT][SEG]
-    f32x4* sAff = reinterpret_cast<f32x4*>(sB + (wres ? nblk : 2) * NT * SEG);   // [2][16] (mean, A, B, -)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -809,20 +851,30 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         return u;
     };
     auto is_edge = [&](const Tile& t) { return t.y0 == 0 || t.x0 == 0 || t.y0 + 16 == p.H || t.x0 + 16 == p.W; };
-    int t_ly[AIT], t_lx[AIT], t_lds[AIT];
+    const int part = tid & 3;                    // this thread's four channels of every 16-channel block
+    int t_ly[NCH], t_lx[NCH], t_lds[NCH];        // tile-local coordinates / LDS offset of the chunks this thread stages
 #pragma unroll
-    for (int it = 0; it < AIT; ++it) {
-        const int idx = tid + it * NTHR;
-        t_ly[it] = idx / LW - 1; t_lx[it] = idx % LW - 1;
-        t_lds[it] = idx < LH * LW ? (idx / LW) * RS + (idx % LW) * 16 : -1;
+    for (int k = 0; k < NCH; ++k) {
+        const int idx = (tid + k * NTHR) >> 2;   // pixel of the halo tile
+        t_ly[k] = idx / LW - 1; t_lx[k] = idx % LW - 1;
+        t_lds[k] = idx < LH * LW ? (idx / LW) * RS + (idx % LW) * 16 + part * 4 : -1;
     }
-    auto tile_pixels = [&](const Tile& t, TilePixel (&tp)[AIT]) {
+    int t_rel[NCH];                              // pixel offset from the tile origin (0 for an idle chunk: any valid pixel)
 #pragma unroll
-        for (int it = 0; it < AIT; ++it) {
-            const int gy = t.y0 + t_ly[it], gx = t.x0 + t_lx[it];
-            const bool inside = t_lds[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            tp[it].lds = t_lds[it];
-            tp[it].pix = inside ? (t.n * p.H + gy) * p.W + gx : -1;
+    for (int k = 0; k < NCH; ++k) t_rel[k] = t_lds[k] >= 0 ? t_ly[k] * p.W + t_lx[k] : 0;
+    auto tile_chunks = [&](const Tile& t, Chunk (&tp)[NCH]) {
+        const int base = (t.n * p.H + t.y0) * p.W + t.x0;
+        if (t.y0 == 0 || t.x0 == 0 || t.y0 + 16 == p.H || t.x0 + 16 == p.W) {      // wave-uniform: only edge tiles test their pixels
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int gy = t.y0 + t_ly[k], gx = t.x0 + t_lx[k];
+                const bool inside = t_lds[k] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                tp[k].lds = t_lds[k];
+                tp[k].pix = inside ? base + t_rel[k] : -1;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { tp[k].lds = t_lds[k]; tp[k].pix = base + t_rel[k]; }
         }
     };
     // A operand: the 4x4 input patch of this lane's Winograd tile (halo coordinates), k slot kq
@@ -837,7 +889,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         for (int nt = 0; nt < NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const bool has_aff = p.aff0 != nullptr;
-    f32x4 ra[AIT][4], rb[BIT], rf;
+    f32x4 ra[NCH], rb[BIT], raff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) raff[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* wgrp = p.wpk + (size_t)g * NT * nblk * SEG;      // U panels of this output-channel group: [q][cb][SEG]
     int wsrc[BIT];                                   // this thread's pieces of a block: q*nblk*SEG + 4r floats
 #pragma unroll
@@ -845,35 +899,31 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         const int i = tid + j * NTHR;
         wsrc[j] = (i / NB4) * nblk * SEG + (i % NB4) * 4;
     }
-    auto load_item = [&](const Tile& t, int cb, const TilePixel (&tp)[AIT]) {
+    auto load_item = [&](const Tile& t, int cb, const Chunk (&tp)[NCH]) {
 #pragma unroll
-        for (int it = 0; it < AIT; ++it) load_pixel(ra[it], p.src0, p.C0, cb * 16, tp[it]);
+        for (int k = 0; k < NCH; ++k) ra[k] = load_chunk(p.src0, p.C0, cb * 16 + part * 4, tp[k]);
         if (!wres) {
 #pragma unroll
             for (int j = 0; j < BIT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wgrp + (size_t)cb * SEG + wsrc[j]);
         }
-        if (has_aff) rf = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0 + cb * 16)[tid & 15];
+        if (has_aff) load_aff4(raff, p.aff0, (size_t)t.n * p.C0 + cb * 16 + part * 4);     // travels with the item
     };
-    auto write_aff_item = [&](int slot) {
-        if (has_aff && tid < 16) sAff[slot * 16 + tid] = rf;
-    };
-    auto write_item = [&](const TilePixel (&tp)[AIT], bool edge, int buf) {
+    auto write_item = [&](const Chunk (&tp)[NCH], bool edge, int buf) {
         float* a_img = sA + buf * (LH * RS);
-        const float4* tab = reinterpret_cast<const float4*>(sAff) + buf * 16;
         if (has_aff) {
             if (edge) {
 #pragma unroll
-                for (int it = 0; it < AIT; ++it) store_pixel<true, false, true>(a_img, ra[it], tab, tp[it]);
+                for (int k = 0; k < NCH; ++k) store_chunk<true, false, true>(a_img, ra[k], raff, tp[k]);
             } else {
 #pragma unroll
-                for (int it = 0; it < AIT; ++it) store_pixel<true, false, false>(a_img, ra[it], tab, tp[it]);
+                for (int k = 0; k < NCH; ++k) store_chunk<true, false, false>(a_img, ra[k], raff, tp[k]);
             }
         } else if (edge) {
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<false, false, true>(a_img, ra[it], tab, tp[it]);
+            for (int k = 0; k < NCH; ++k) store_chunk<false, false, true>(a_img, ra[k], raff, tp[k]);
         } else {
 #pragma unroll
-            for (int it = 0; it < AIT; ++it) store_pixel<false, false, false>(a_img, ra[it], tab, tp[it]);
+            for (int k = 0; k < NCH; ++k) store_chunk<false, false, false>(a_img, ra[k], raff, tp[k]);
         }
         if (!wres) {
 #pragma unroll
@@ -1058,12 +1108,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         tc.x0 = tx * 16; tc.y0 = (r % p.tiles_y) * 16; tc.n = r / p.tiles_y; tc.row = (r % p.tiles_y) * p.tiles_x + tx;
     }
     int cb = 0, cbr = 0;
-    TilePixel tpr[AIT];
-    auto next_item = [&](int i, Tile& t, int& cbi, TilePixel (&tp)[AIT]) {
+    Chunk tpr[NCH];
+    auto next_item = [&](int i, Tile& t, int& cbi, Chunk (&tp)[NCH]) {
         if (i + 1 >= total_items) return;
-        if (++cbi == nblk) { cbi = 0; t = advance(t); tile_pixels(t, tp); }
+        if (++cbi == nblk) { cbi = 0; t = advance(t); tile_chunks(t, tp); }
     };
-    tile_pixels(tc, tpr);
+    tile_chunks(tc, tpr);
     if (wres) {
         for (int cbk = 0; cbk < nblk; ++cbk) {
 #pragma unroll
@@ -1073,32 +1123,37 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         }
     }
     load_item(tc, cb, tpr);
-    if (has_aff) {
-        write_aff_item(0);
-        __syncthreads();
-    }
     write_item(tpr, is_edge(tc), 0);
     tr = tc; cbr = cb;
     next_item(0, tr, cbr, tpr);
     load_item(tr, cbr, tpr);
-    write_aff_item(1);
     __syncthreads();
+    unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, sw = 0, sl = 0, sm = 0, se = 0, sb = 0;
+    (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)k5; (void)sw; (void)sl; (void)sm; (void)se; (void)sb;
     for (int it = 0; it < total_items; ++it) {
         const bool has_next = it + 1 < total_items;
+        TICK(k0);
         if (has_next) write_item(tpr, is_edge(tr), (it + 1) & 1);
+        TICK(k1);
         if (cb == nblk - 1) epilogue_loads(tc);
         Tile t2 = tr; int cb2 = cbr;
         next_item(it + 1, t2, cb2, tpr);
         load_item(t2, cb2, tpr);
+        TICK(k2);
         wino_item(it & 1, cb);
+        TICK(k3);
         if (cb == nblk - 1) {
             epilogue(tc);
             if (stats_direct && (!has_next || tr.n != tc.n)) flush_stats(tc);
         }
-        write_aff_item(it & 1);
+        TICK(k4);
         __syncthreads();
+        TICK(k5);
+        TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4); TSUM(sb, k4, k5);
         tc = tr; cb = cbr; tr = t2; cbr = cb2;
     }
+    TFLUSH(6, sw); TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(9, se); TFLUSH(10, sb);
+    TFLUSH(12, (unsigned long long)total_items); TFLUSH(15, 1ull);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1697,6 +1752,110 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
             const float q = (v[0][j] * v[0][j] + v[1][j] * v[1][j]) + (v[2][j] * v[2][j] + v[3][j] * v[3][j]);
             atomicAdd(&sstat[c + j], to_fixed(s, kStatScale1));
             atomicAdd(&sstat[p.C + c + j], to_fixed(q, kStatScale2));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.C; i += 256) {
+        StatPart sp; sp.s1 = sstat[i]; sp.s2 = sstat[p.C + i];
+        p.partials[((size_t)n * p.prow + blockIdx.x) * p.C + i] = sp;
+    }
+}
+
+// post_kernel for the large planes: one thread = 4 consecutive x, 4 consecutive channels and RPT consecutive rows.  The 3-row
+// blur window slides down in registers, so a row of inputs is loaded once per RPT+2 output rows... per thread (6 float4 per
+// new row instead of 18 per output row: the first form was bound by its load instructions, 3.5-4.1 TB/s), the loads of row
+// r+2 are in flight while row r is computed, and the statistics of the RPT rows stay in registers until the end.
+// Same arithmetic in the same order per output (9-tap fmaf chain ky, kx ascending; zero padding = zeroed values).
+template <int RPT>
+__global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sstat[];   // [2][C]
+    const int n = blockIdx.y;
+    const int C4 = p.C >> 2, W4 = p.W >> 2;
+    const int total = (p.H / RPT) * W4 * C4;
+    for (int i = threadIdx.x; i < 2 * p.C; i += 256) sstat[i] = 0ull;
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < total) {
+        const int cq = idx % C4, t = idx / C4;
+        const int xq = t % W4, y0 = (t / W4) * RPT;
+        const int c = cq * 4, x0 = xq * 4;
+        const float* src = p.src + (size_t)n * p.H * p.W * p.C + c;
+        float wk[4][9];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) wk[j][tp] = p.blur[(c + j) * 9 + tp];
+        const float4 sf = *reinterpret_cast<const float4*>(p.nscale + c);
+        const float4 nb = *reinterpret_cast<const float4*>(p.nbias + c);
+        const float sfv[4] = {sf.x, sf.y, sf.z, sf.w}, nbv[4] = {nb.x, nb.y, nb.z, nb.w};
+        int xoff[6];
+        bool xin[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int xx = x0 - 1 + k;
+            xin[k] = xx >= 0 && xx < p.W;
+            xoff[k] = (xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx)) * p.C;
+        }
+        auto load_row = [&](float4 (&row)[6], int yy) {      // unconditional loads (clamped), padding = zeroed values
+            const bool vy = yy >= 0 && yy < p.H;
+            const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+            const float* rp = src + (size_t)yc * p.W * p.C;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                row[k] = *reinterpret_cast<const float4*>(rp + xoff[k]);
+                if (!(vy && xin[k])) row[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        float4 win[4][6];                                   // rows y-1, y, y+1 and the prefetched y+2 (ring of four)
+        load_row(win[0], y0 - 1);
+        load_row(win[1], y0);
+        load_row(win[2], y0 + 1);
+        unsigned long long I1[4] = {0, 0, 0, 0}, I2[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int y = y0 + r;
+            if (r + 1 < RPT) load_row(win[(r + 3) & 3], y + 2);      // in flight during this row's arithmetic
+            const float4 nz = *reinterpret_cast<const float4*>(p.noise + ((size_t)n * p.H + y) * p.W + x0);
+            const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
+            float v[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[q][j] = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 tv = win[(r + ky) & 3][q + kx];
+                        v[q][0] = fmaf(tv.x, wk[0][ky * 3 + kx], v[q][0]);
+                        v[q][1] = fmaf(tv.y, wk[1][ky * 3 + kx], v[q][1]);
+                        v[q][2] = fmaf(tv.z, wk[2][ky * 3 + kx], v[q][2]);
+                        v[q][3] = fmaf(tv.w, wk[3][ky * 3 + kx], v[q][3]);
+                    }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float tn = sfv[j] * nzv[q];
+                    v[q][j] = lrelu((v[q][j] + tn) + nbv[j]);
+                }
+                *reinterpret_cast<float4*>(p.out + (((size_t)n * p.H + y) * p.W + x0 + q) * p.C + c) =
+                    make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float sq = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
+                const float qq = (v[0][j] * v[0][j] + v[1][j] * v[1][j]) + (v[2][j] * v[2][j] + v[3][j] * v[3][j]);
+                I1[j] += to_fixed(sq, kStatScale1);
+                I2[j] += to_fixed(qq, kStatScale2);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&sstat[c + j], I1[j]);
+            atomicAdd(&sstat[p.C + c + j], I2[j]);
         }
     }
     __syncthreads();
@@ -2352,7 +2511,7 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int RS = 18 * 16 + 4, SEG = 16 * 256;
     const int nblk = p.C0 / 16;
     const bool wres = (size_t)nblk * NT * SEG * sizeof(float) <= (NT == 1 ? 36 : 72) * 1024;      // whole panel of the group resident (<= 32 input channels)
-    const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * NT * SEG) + 32 * sizeof(float4);
+    const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * NT * SEG);
     auto kern = conv3x3_wino<EPI, NT>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
@@ -2624,12 +2783,30 @@ hipError_t launch_subpixel(const ConvParams& p, int epi, bool sc, int n, hipStre
     return hipErrorInvalidValue;
 }
 
+// rows per thread of the blurred form: 4 from 64 px on (enough threads to fill the chip), else the one-row kernel
+static int post_rpt(const PostParams& p) {
+    static const int forced = getenv("GSA_POST_RPT") ? atoi(getenv("GSA_POST_RPT")) : -1;
+    if (!p.blur || !p.src_per_sample || p.H % 8) return 1;
+    if (forced >= 0) return forced == 8 ? 8 : (forced == 4 ? 4 : (forced == 2 ? 2 : 1));
+    return p.H >= 64 ? 4 : 1;
+}
+
+int post_rows_used(const PostParams& p) {
+    const int rpt = post_rpt(p);
+    return rpt == 1 ? post_prow(p.H, p.W, p.C) : ((p.H / rpt) * (p.W / 4) * (p.C / 4) + 255) / 256;
+}
+
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
     if (p.W % 4 || p.C % 4) return hipErrorInvalidValue;
     PostParams q = p;
-    q.prow = post_prow(p.H, p.W, p.C);
+    const int rpt = post_rpt(p);
+    q.prow = post_rows_used(p);
     dim3 grid(q.prow, n);
-    hipLaunchKernelGGL(post_kernel, grid, dim3(256), sizeof(unsigned long long) * 2 * p.C, s, q);
+    const size_t lds = sizeof(unsigned long long) * 2 * p.C;
+    if (rpt == 8) hipLaunchKernelGGL(post_rows_kernel<8>, grid, dim3(256), lds, s, q);
+    else if (rpt == 4) hipLaunchKernelGGL(post_rows_kernel<4>, grid, dim3(256), lds, s, q);
+    else if (rpt == 2) hipLaunchKernelGGL(post_rows_kernel<2>, grid, dim3(256), lds, s, q);
+    else hipLaunchKernelGGL(post_kernel, grid, dim3(256), lds, s, q);
     return hipGetLastError();
 }
 
