@@ -314,7 +314,12 @@ def main():
         # FLOP the kernels really execute (the sub-pixel form of nearest-x2 + conv3x3 needs 4 taps instead of 9 and the
         # 1x1 shortcuts run at input resolution): what the MFMA roofline of the whole step is priced on
         exec_gflop = sum(e["flops"] for e in entries) / args.steps / B / 1e9
-        ach = top["flops"] / (top["ms"] * 1e-3) / 1e12 if top["ms"] > 0 else 0.0
+        # `achieved` follows the bench contract: ALGORITHMIC FLOP per launch (the layer in the reference's formulation: 2*MACs
+        # of the direct convolution) / the launch time.  The kernel may execute fewer (Winograd F(2x2,3x3):
+        # 16 products per 2x2 outputs instead of 36; sub-pixel form: 4 taps instead of 9): `executed_*` is what the matrix
+        # cores really issue, i.e. the utilisation of the MFMA pipe.
+        ach = top["alg_flops"] / (top["ms"] * 1e-3) / 1e12 if top["ms"] > 0 else 0.0
+        ach_exec = top["flops"] / (top["ms"] * 1e-3) / 1e12 if top["ms"] > 0 else 0.0
         tr = pmc_traffic(top["name"])
         bound, peak, unit = "mfma", PEAK_FP32_TFLOPS, "TFLOP/s"
         if args.precision == "bf16":     # 16x the MFMA rate: the same kernels sit under the HBM roof
@@ -322,12 +327,14 @@ def main():
             ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9 if top["ms"] > 0 else 0.0
         roofline = {"bound": bound, "kernel": top["name"], "achieved": round(ach, 3), "peak": peak,
                     "unit": unit, "frac": round(ach / peak, 4),
+                    "executed_tflops": round(ach_exec, 3), "executed_frac_of_mfma_peak": round(ach_exec / PEAK_FP32_TFLOPS, 4),
                     "avg_launch_ms": round(top["ms"] / max(1, top["launches"]), 4),
                     "launches": top["launches"],
                     "measured": "HIP events around every launch in a second pass of the same K steps, run right "
                                 "after the timed region with the decoder-beside-synthesis stream overlap off "
                                 "(durations not stretched by a concurrent kernel)",
-                    "flops_per_launch": round(top["flops"] / max(1, top["launches"])),
+                    "flops_per_launch": round(top["alg_flops"] / max(1, top["launches"])),
+                    "executed_flops_per_launch": round(top["flops"] / max(1, top["launches"])),
                     "algorithmic_bytes_per_launch": round(top["bytes"] / max(1, top["launches"])),
                     "traffic": tr["bytes_per_launch"] if tr else None,
                     "traffic_source": tr["source"] if tr else None}
@@ -366,14 +373,16 @@ def main():
             # the bytes the timed configuration produced (rank 0, sample 0 of the last timed step) against the C oracle
             "output": output_check(args.gan, B, args.precision, out_img, out_mask),
             "kernels": [{"name": e["name"], "ms_per_step": round(e["ms"] / args.steps, 3),
-                         "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else 0.0,
+                         "tflops": round(e["alg_flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else 0.0,
+                         "executed_tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else 0.0,
                          "gbs": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 1) if e["ms"] > 0 else 0.0}
                         for e in entries[:8]],
         }
         if args.layers:
             for e in entries:
-                print("%-70s %8.3f ms/step %7.2f TF/s %8.1f GB/s" % (
+                print("%-70s %8.3f ms/step %7.2f TF/s executed (%7.2f algorithmic) %8.1f GB/s" % (
                     e["name"], e["ms"] / args.steps, e["flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] else 0,
+                    e["alg_flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] else 0,
                     e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["ms"] else 0), file=sys.stderr)
         wall = {"setup": round(t_setup, 2), "warmup": round(t_warm, 3), "timed": round(dt, 4), "profile_pass": round(t_prof, 3)}
         if world == 1 and not args.no_secondary:

@@ -82,7 +82,7 @@ class Api:
             "profile_collect": (c.c_int, [vp]),
             "profile_entry": (c.c_int, [vp, i32, c.POINTER(c.c_char_p), c.POINTER(c.c_double),
                                         c.POINTER(c.c_int64), c.POINTER(c.c_double),
-                                        c.POINTER(c.c_double)]),
+                                        c.POINTER(c.c_double), c.POINTER(c.c_double)]),
             "profile_reset": (c.c_int, [vp]),
             "version": (c.c_char_p, []),
         }
@@ -235,11 +235,11 @@ class Context:
         out = []
         for i in range(n):
             name = ctypes.c_char_p()
-            ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            ms, fl, by, af = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
             cnt = ctypes.c_int64()
             self._check(self.api.profile_entry(self._h, i, ctypes.byref(name), ctypes.byref(ms),
-                                               ctypes.byref(cnt), ctypes.byref(fl), ctypes.byref(by)),
+                                               ctypes.byref(cnt), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(af)),
                         "profile_entry")
             out.append({"name": name.value.decode(), "ms": ms.value, "launches": cnt.value,
-                        "flops": fl.value, "bytes": by.value})
+                        "flops": fl.value, "bytes": by.value, "alg_flops": af.value})
         return out

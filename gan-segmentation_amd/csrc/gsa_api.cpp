@@ -60,7 +60,7 @@ struct DecLevelDev {
 
 struct ProfEntry {
     std::string name;
-    double ms = 0, flops = 0, bytes = 0;
+    double ms = 0, flops = 0, bytes = 0, alg_flops = 0;   // flops: executed by the kernel; alg_flops: of the reference's formulation
     int64_t launches = 0;
 };
 
@@ -415,7 +415,9 @@ struct Launch {
     std::string kname_s;
     const char* kname = "";
     const char* label = nullptr;
-    Launch(gsa_ctx* ctx, hipStream_t st, const char* kernel, const char* layer, double flops, double bytes) : c(ctx), s(st) {
+    // flops = FLOP the kernel executes; alg = FLOP of the same layer in the reference's formulation (2*MACs of the direct
+    // 9-tap / 16-tap convolution) when the kernel uses a cheaper form (sub-pixel, Winograd); < 0: the same
+    Launch(gsa_ctx* ctx, hipStream_t st, const char* kernel, const char* layer, double flops, double bytes, double alg = -1.0) : c(ctx), s(st) {
         kname_s = kernel; kname = kname_s.c_str(); label = layer;
         if (!c->prof) return;
         std::string key = kernel;
@@ -429,6 +431,7 @@ struct Launch {
             entry = (int)c->prof_entries.size() - 1;
         }
         c->prof_entries[entry].flops += flops;
+        c->prof_entries[entry].alg_flops += alg < 0 ? flops : alg;
         c->prof_entries[entry].bytes += bytes;
         c->prof_entries[entry].launches += 1;
         auto get = [&]() {
@@ -914,7 +917,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                         snprintf(layer, sizeof layer, B.is_deconv ? "g.%d.deconv_1" : "g.%d.conv_1", R);
                         static thread_local char kn[128];
                         snprintf(kn, sizeof kn, "%s", subpixel_kernel_name(cp, EPI_RAW, false, n));
-                        Launch lp(c, s, kn, layer, 2.0 * px * C * Cin * 4, 4.0 * (px / 4 * Cin + px * C));
+                        Launch lp(c, s, kn, layer, 2.0 * px * C * Cin * 4, 4.0 * (px / 4 * Cin + px * C), B.is_deconv ? -1.0 : 2.0 * px * C * Cin * 9);
                         HIP_TRY(launch_subpixel(cp, EPI_RAW, false, n, s));
                     } else {
                         cp.up = 1;
@@ -937,7 +940,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 snprintf(layer, sizeof layer, "g.%d.conv_2", R);
                 int rows = conv_stat_rows(R, R, C, n);
                 cp.stat_rows_host = &rows;            // the launcher reports the partial rows it used
-                Launch lp(c, s, conv_kernel_name(cp, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * (conv_uses_wino(cp, EPI_SYNTH, false) ? 4 : 9), 4.0 * (2 * px * C + px));
+                Launch lp(c, s, conv_kernel_name(cp, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * (conv_uses_wino(cp, EPI_SYNTH, false) ? 4 : 9), 4.0 * (2 * px * C + px), 2.0 * px * C * C * 9);
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
                 prow = rows;
             }
@@ -985,7 +988,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             cp.wpk = d.cvt_w; cp.wino = d.cvt_u; cp.Cout = d.F; cp.out = c->cvt[i];
             cp.bias = d.cvt_b; cp.bn_s = d.cvt_s; cp.bn_rm = d.cvt_rm; cp.bn_beta = d.cvt_beta;
             snprintf(layer, sizeof layer, "d.cvt_%d", i);
-            Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * (conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px * (d.I + d.F));
+            Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * (conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px * (d.I + d.F), 2.0 * px * d.F * d.I * 9);
             HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
         }
         if (!d.is_last) {
@@ -1004,7 +1007,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                     static thread_local char kn[128];
                     snprintf(kn, sizeof kn, "%s", subpixel_kernel_name(cp, EPI_DEC, d.has_sc, n));
                     Launch lp(c, s, kn, layer, 2.0 * px2 * d.cs * d.in_c * 4 + (d.has_sc ? 2.0 * px * d.cs * d.in_c : 0.0),
-                              4.0 * (px * d.in_c + px2 * d.cs + (d.has_sc ? px * d.cs : 0.0)));
+                              4.0 * (px * d.in_c + px2 * d.cs + (d.has_sc ? px * d.cs : 0.0)), 2.0 * px2 * d.cs * d.in_c * (9 + (d.has_sc ? 1 : 0)));
                     cp.up = 0;
                     HIP_TRY(launch_subpixel(cp, EPI_DEC, d.has_sc, n, s));
                 } else {
@@ -1023,7 +1026,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 else if (i == s0) { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 else { cp.resid = c->prev[i - 1]; cp.resid1 = c->cvt[i]; cp.res_c0 = d.F; cp.resid_up = 1; }   // ... over concat(prev, cvt)
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
-                Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * (conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px2 * d.cs * 3);
+                Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * (conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px2 * d.cs * 3, 2.0 * px2 * d.cs * d.cs * 9);
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
             }
         } else {
@@ -1091,11 +1094,10 @@ int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const floa
     // stream beside the synthesis of the higher levels (fork/join through events, no host
     // synchronisation, graph-capturable): its short, latency-bound low-resolution kernels then hide behind
     // the synthesis kernels and the tails of either side are filled by the other.
-    // Measured on MI355X: below 8 samples per call the chip has room beside the synthesis kernels
-    // (FFHQ fp32: +15 % at 1, +8 % at 2, +4 % at 4, +3 % at 6), and in bf16 mode at every batch size (kernels 2-3x
-    // shorter: +5 % at 8, +7 % at 16); in fp32 from 8 samples on every large kernel is persistent and fills the chip,
-    // and a second stream only costs (-0.7 % FFHQ batch 8, -1.6..-3.9 % bedrooms batch 64 / 16).
-    const int want = c->side_levels < 0 ? ((c->bf16 || n < 8) ? c->d_n - 1 : 0) : c->side_levels;
+    // Measured on MI355X, round-2 kernels (Winograd / K-split forms: shorter kernels with more
+    // non-MFMA time for a neighbour to fill): FFHQ fp32 +18 % at 1 sample, +5.7 % at 4, +2.3 % at 8 -- so the decoder
+    // levels below the last always go to the side stream (gsa_set_overlap / GSA_SIDE_LEVELS override it).
+    const int want = c->side_levels < 0 ? c->d_n - 1 : c->side_levels;
     const int ns = want > c->d_n - 1 ? c->d_n - 1 : want;
     if (ns > 0) {
         HIP_TRY(hipEventRecord(c->ev_fork, s));
@@ -1181,7 +1183,8 @@ int gsa_profile_collect(gsa_ctx* c) {
     return (int)c->prof_entries.size();
 }
 
-int gsa_profile_entry(gsa_ctx* c, int32_t i, const char** name, double* ms, int64_t* launches, double* flops, double* bytes) {
+int gsa_profile_entry(gsa_ctx* c, int32_t i, const char** name, double* ms, int64_t* launches, double* flops, double* bytes,
+                      double* alg_flops) {
     if (!c || i < 0 || i >= (int)c->prof_entries.size()) return GSA_ERR_INVALID;
     const ProfEntry& e = c->prof_entries[i];
     if (name) *name = e.name.c_str();
@@ -1189,6 +1192,7 @@ int gsa_profile_entry(gsa_ctx* c, int32_t i, const char** name, double* ms, int6
     if (launches) *launches = e.launches;
     if (flops) *flops = e.flops;
     if (bytes) *bytes = e.bytes;
+    if (alg_flops) *alg_flops = e.alg_flops;
     return GSA_OK;
 }
 

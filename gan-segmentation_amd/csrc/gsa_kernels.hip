@@ -37,6 +37,11 @@
 #ifndef GSA_NO_XCD_REMAP
 #define GSA_NO_XCD_REMAP 0
 #endif
+// double-buffered (prefetch two items ahead, one barrier per item) form also for the 8x8 / 4x4 tiles of the 4^2-16^2 layers:
+// their 32 channel blocks were 32 dependent load -> LDS -> barrier rounds with ONE block in flight per workgroup
+#ifndef GSA_DB_SMALL
+#define GSA_DB_SMALL 1
+#endif
 
 namespace gsa {
 
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
     // write of item i+1 no longer has to wait for the readers of item i, so it sits in front of
     // the MFMAs of item i in the same wave (one barrier per item instead of two) and its VALU/LDS
     // instructions issue in the gaps of the MFMA stream
-    constexpr bool DB = Q <= 2 && !SC && TH == 16;
+    constexpr bool DB = Q <= 2 && !SC && (TH == 16 || GSA_DB_SMALL);
     constexpr int NBUF = DB ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                            // [NBUF][LH*RS]
@@ -798,6 +803,183 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #endif
     STAMP(5);                                      // [4,5): last stores retired
     STAMP_FLUSH(5);
+}
+
+// ------------------------------------------------------------------------------------------
+// conv3x3 with a 4-WAY K SPLIT for the low-resolution layers (>= 64 input channels, one source; outputs <= 8 px, or <= 32 px
+// with at most 32 output channels: the layers whose tiles cannot fill the chip).
+//
+// The 512-channel layers at 4^2-32^2 used to be ONE dependent chain of 1152 MFMAs per output tile behind 32
+// load -> LDS -> barrier rounds (one wave per SIMD, every phase serialised: ~50 us whatever the batch).  Here the four waves
+// of a workgroup each accumulate one contiguous QUARTER of the 16-channel blocks over ALL patches of the tile
+// (4 independent chains per wave at 8x8), an item stages four blocks (one per wave) per barrier, and the partial sums are
+// combined through LDS in the fixed order (s0 + s1) + (s2 + s3) -- the canonical arithmetic of these layers (DESIGN.md;
+// oracle conv3x3 use_ksplit), so the result is still bit-exact and batch-independent.
+// Workgroup = one TH x TH tile (TH = 4, 8) x 16 output channels of one sample.
+template <int TH, int EPI, bool BF>
+__global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
+    constexpr int NTHR = 256, MT = (TH / 4) * (TH / 4), PW = TH / 4;
+    constexpr int LH = TH + 2, LW = TH + 2;
+    constexpr int PX = BF ? 8 : 16, TS = BF ? 128 : 256, KQ = BF ? 2 : 4;
+    constexpr int RS = LW * PX + (BF ? 4 : 8);
+    constexpr int SEG = 9 * TS, IMG = LH * RS;
+    constexpr int NB4 = 4 * SEG / 4, BIT = (NB4 + NTHR - 1) / NTHR;         // weights of an item: four blocks
+    static_assert(LH * LW <= NTHR, "one staged pixel per thread and block");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                                 // [2][4][IMG]
+    float* sB = sA + 2 * 4 * IMG;                     // [2][4][SEG]
+    f32x4* sAff = reinterpret_cast<f32x4*>(sB + 2 * 4 * SEG);     // [2][4][16]
+    f32x4* sP = sAff + 2 * 4 * 16;                    // [4 quarters][MT][64 lanes] partial accumulators
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = K quarter
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    const int g = blockIdx.y, n = blockIdx.z;
+    const int y0 = ty * TH, x0 = tx * TH;
+    const int nblk = p.C0 >> 4, nq = nblk >> 2;       // items per tile = blocks per quarter
+    const bool has_aff = p.aff0 != nullptr;
+
+    TilePixel tp;
+    {
+        const int ly = tid / LW, lx = tid % LW;
+        const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+        const bool stage = tid < LH * LW;
+        const bool inside = stage && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        tp.lds = stage ? ly * RS + lx * PX : -1;
+        tp.pix = inside ? (n * p.Hs + (gy >> p.up)) * p.Ws + (gx >> p.up) : -1;
+    }
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        abase[mt] = ((mt / PW) * 4 + (i16 >> 2)) * RS + ((mt % PW) * 4 + (i16 & 3)) * PX + kq * KQ;
+    const int bbase = (kq * 16 + i16) * KQ;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[4][4], rb[BIT], rf;
+    rf = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wgrp = p.wpk + (size_t)g * nblk * SEG;
+    auto load_item = [&](int it) {                    // blocks q*nq + it, q = 0..3
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_pixel(ra[q], p.src0, p.C0, (q * nq + it) * 16, tp);
+#pragma unroll
+        for (int j = 0; j < BIT; ++j) {
+            const int i = min(tid + j * NTHR, NB4 - 1);
+            const int q = i / (SEG / 4), r = i % (SEG / 4);
+            rb[j] = reinterpret_cast<const f32x4*>(wgrp + (size_t)(q * nq + it) * SEG)[r];
+        }
+        if (has_aff && tid < 64) rf = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)n * p.C0 + ((tid >> 4) * nq + it) * 16)[tid & 15];
+    };
+    auto write_aff = [&](int buf) {
+        if (has_aff && tid < 64) sAff[buf * 64 + tid] = rf;
+    };
+    auto write_item = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* a_img = sA + (buf * 4 + q) * IMG;
+            const float4* tab = reinterpret_cast<const float4*>(sAff) + (buf * 4 + q) * 16;
+            if (has_aff) store_pixel<true, BF, true>(a_img, ra[q], tab, tp);
+            else store_pixel<false, BF, true>(a_img, ra[q], tab, tp);
+        }
+#pragma unroll
+        for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * 4 * SEG)[min(tid + j * NTHR, NB4 - 1)] = rb[j];
+    };
+    auto mfma_item = [&](int buf) {                   // this wave's block of the item
+        const float* a_img = sA + (buf * 4 + wave) * IMG;
+        const float* b_img = sB + (buf * 4 + wave) * SEG + bbase;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * RS + (tap % 3) * PX;
+            if constexpr (BF) {
+                const s16x4 b = *reinterpret_cast<const s16x4*>(b_img + tap * TS);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(a_img + abase[mt] + toff), b, acc[mt], 0, 0, 0);
+            } else {
+                f32x4 a[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_img + abase[mt] + toff);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(b_img + tap * 256);
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[cg], acc[mt], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- items: double-buffered LDS, item it+1 in registers, item it+2 in flight
+    load_item(0);
+    write_aff(0);
+    __syncthreads();
+    write_item(0);
+    load_item(min(1, nq - 1));
+    write_aff(1);
+    __syncthreads();
+    for (int it = 0; it < nq; ++it) {
+        if (it + 1 < nq) write_item((it + 1) & 1);
+        load_item(min(it + 2, nq - 1));
+        mfma_item(it & 1);
+        write_aff(it & 1);            // entries of item it+2 -> the slot item it used (its reader ran in iteration it-1); read after the barrier
+        __syncthreads();              // readers of buffer it&1 done; buffer (it+1)&1 complete
+    }
+    // ---- combine the four quarters in the fixed order (s0 + s1) + (s2 + s3); wave w finishes patch w
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) sP[(wave * MT + mt) * 64 + lane] = acc[mt];
+    __syncthreads();
+    if (wave >= MT) return;
+    const int mt = wave;
+    const f32x4 s01 = sP[(0 * MT + mt) * 64 + lane] + sP[(1 * MT + mt) * 64 + lane];
+    const f32x4 s23 = sP[(2 * MT + mt) * 64 + lane] + sP[(3 * MT + mt) * 64 + lane];
+    const f32x4 tot = s01 + s23;
+    float v[4] = {tot[0], tot[1], tot[2], tot[3]};
+    // ---- epilogue of patch mt: C layout lane -> (channel = lane & 15, patch row = lane >> 4), reg -> x
+    const int pr = mt / PW, pc = mt % PW, prow = lane >> 4;
+    const int co = g * 16 + i16;
+    const int y = y0 + pr * 4 + prow, xb = x0 + pc * 4;
+    const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;
+    if (EPI == EPI_SYNTH) {
+        const float4 nz = *reinterpret_cast<const float4*>(p.noise + ((size_t)(n * p.H + y) * p.W + xb));
+        const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
+        const float e0 = p.nscale[co], e1 = p.nbias[co];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = e0 * nzv[r];
+            v[r] = lrelu((v[r] + t) + e1);
+        }
+        const float sq = (v[0] + v[1]) + (v[2] + v[3]);
+        const float qq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        unsigned long long I1 = to_fixed(sq, kStatScale1), I2 = to_fixed(qq, kStatScale2);
+        I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
+        I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
+        if (lane < 16) {
+            StatPart sp; sp.s1 = I1; sp.s2 = I2;
+            p.partials[((size_t)n * p.prow + blockIdx.x * MT + mt) * p.Cout + co] = sp;
+        }
+    }
+    if (EPI == EPI_DEC) {
+        const float e0 = p.bias[co], e1 = p.bn_rm[co], e2 = p.bn_s[co], e3 = p.bn_beta[co];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float yv = v[r] + e0;
+            v[r] = lrelu(fmaf(yv - e1, e2, e3));
+        }
+    }
+    f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
+    if (EPI == EPI_DEC && p.resid != nullptr) {
+        const int ru = p.resid_up;
+        const size_t rpix = (size_t)(n * (p.H >> ru) + (y >> ru)) * (p.W >> ru) + ((xb + xj) >> ru);
+        const int cch = g * 16;
+        const bool second = p.resid1 != nullptr && cch >= p.res_c0;
+        const int rcs = second ? p.Cout - p.res_c0 : (p.resid1 ? p.res_c0 : p.Cout);
+        const float* rsrc = (second ? p.resid1 : p.resid) + rpix * rcs + (second ? cch - p.res_c0 : cch) + cq4;
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(rsrc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vt[r] = rr[r] + vt[r];
+    }
+    *reinterpret_cast<f32x4*>(p.out + ((size_t)(n * p.H + y) * p.W + xb + xj) * p.Cout + g * 16 + cq4) = vt;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2413,7 +2595,7 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int Q = NT * WN, COUT_T = 16 * Q;
     constexpr int TS = BF ? 128 : 256;
     constexpr int RS = (TW + 2) * (BF ? 8 : 16) + (BF ? 4 : 8);
-    constexpr int NBUF = (Q <= 2 && !SC && TH == 16) ? 2 : 1;   // must match the kernel's DB
+    constexpr int NBUF = (Q <= 2 && !SC && (TH == 16 || GSA_DB_SMALL)) ? 2 : 1;   // must match the kernel's DB
     // resident weights: one channel group and a whole panel of at most 40 KB (see the kernel)
     const int nblk_all = (p.C0 + p.C1) / 16;
     static const bool wres_enabled = !(getenv("GSA_WRES") && atoi(getenv("GSA_WRES")) == 0);
@@ -2487,6 +2669,48 @@ template <int TH, int TW, int WM, int WN, int NT>
 static hipError_t launch_conv_e(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     return p.bf16 ? launch_conv_b<TH, TW, WM, WN, NT, true>(p, epi, sc, n, s)
                   : launch_conv_b<TH, TW, WM, WN, NT, false>(p, epi, sc, n, s);
+}
+
+// ---- 4-way K split (static rule: the same one the oracle applies) -------------------------------------------------------
+bool conv_uses_ksplit(const ConvParams& p, bool sc) {
+    static const bool enabled = !(getenv("GSA_KSPLIT") && atoi(getenv("GSA_KSPLIT")) == 0);
+    return enabled && !sc && p.src1 == nullptr && p.C1 == 0 && p.C0 >= 64 && p.C0 % 64 == 0 && (p.H <= 8 || (p.H <= 32 && p.Cout <= 32)) && p.H == p.W && p.Cout % 16 == 0;
+}
+
+template <int TH, int EPI, bool BF>
+static hipError_t launch_ksplit_t(const ConvParams& p, int n, hipStream_t s) {
+    constexpr int MT = (TH / 4) * (TH / 4), PX = BF ? 8 : 16, TS = BF ? 128 : 256;
+    constexpr int RS = (TH + 2) * PX + (BF ? 4 : 8), IMG = (TH + 2) * RS, SEG = 9 * TS;
+    const size_t lds = sizeof(float) * (2 * 4 * IMG + 2 * 4 * SEG) + sizeof(float4) * (2 * 4 * 16 + 4 * MT * 64);
+    auto kern = conv3x3_ksplit<TH, EPI, BF>;
+    if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
+    static LaunchState states[kMaxDevices];
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        hipError_t e = prepare_kernel(kern, states[p.device]);
+        if (e != hipSuccess) return e;
+    }
+    ConvParams q = p;
+    q.tiles_x = p.W / TH;
+    q.tiles_y = p.H / TH;
+    q.groups = p.Cout / 16;
+    q.prow = q.tiles_x * q.tiles_y * MT;
+    q.stats_direct = 0;
+    if (p.stat_rows_host) *p.stat_rows_host = q.prow;
+    hipLaunchKernelGGL(kern, dim3(q.tiles_x * q.tiles_y, q.groups, n), dim3(256), lds, s, q);
+    return hipGetLastError();
+}
+
+static hipError_t launch_ksplit(const ConvParams& p, int epi, int n, hipStream_t s) {
+#define GSA_KS(TH, BF) \
+    if ((p.H == 4 ? 4 : 8) == TH && (p.bf16 != 0) == BF) { \
+        if (epi == EPI_RAW) return launch_ksplit_t<TH, EPI_RAW, BF>(p, n, s); \
+        if (epi == EPI_SYNTH) return launch_ksplit_t<TH, EPI_SYNTH, BF>(p, n, s); \
+        return launch_ksplit_t<TH, EPI_DEC, BF>(p, n, s); \
+    }
+    GSA_KS(4, false) GSA_KS(8, false) GSA_KS(4, true) GSA_KS(8, true)
+#undef GSA_KS
+    return hipErrorInvalidValue;
 }
 
 // ---- Winograd form ---------------------------------------------------------------------------------------
@@ -2570,6 +2794,10 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d, %d>(gsa::ConvParams)", epi, wino_nt(p));
         return buf;
     }
+    if (conv_uses_ksplit(p, sc)) {
+        snprintf(buf, sizeof buf, "void gsa::conv3x3_ksplit<%d, %d, %s>(gsa::ConvParams)", p.H == 4 ? 4 : 8, epi, p.bf16 ? "true" : "false");
+        return buf;
+    }
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
     snprintf(buf, sizeof buf, "void gsa::conv3x3_mfma<%d, %d, %d, %d, %d, %d, %s, %s>(gsa::ConvParams)", c.th, c.th, c.wm, c.wn, c.nt,
              epi, sc ? "true" : "false", p.bf16 ? "true" : "false");
@@ -2579,6 +2807,7 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     if (p.H != p.W || (p.H & (p.H - 1)) || p.H < 4 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
     if (conv_uses_wino(p, epi, sc)) return launch_wino(p, epi, n, s);
+    if (conv_uses_ksplit(p, sc)) return launch_ksplit(p, epi, n, s);
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
 #define GSA_GEOM(TH, WM, WN, NT) \
     if (c.th == TH && c.wm == WM && c.wn == WN && c.nt == NT) return launch_conv_e<TH, TH, WM, WN, NT>(p, epi, sc, n, s);

@@ -128,8 +128,7 @@ int gsa_generate(gsa_ctx* ctx, void* stream, int32_t n, const float* z,
 
 /* gsa_generate runs the decoder on a second HIP stream beside the synthesis of the higher
  * resolutions (fork/join through events).  `levels` = number of decoder levels placed there; negative = the default:
- * all but the last in bf16 mode and for fp32 calls of fewer than 8 samples, none for larger fp32 calls (the large
- * kernels then fill the chip on their own);
+ * all but the last (measured faster at every batch size with the round-2 kernels);
  * 0 = everything on the caller's stream, used by bench.py's serialized roofline pass so that kernel durations are
  * not stretched by concurrent kernels. */
 int gsa_set_overlap(gsa_ctx* ctx, int32_t levels);
@@ -173,10 +172,12 @@ int gsa_segmentation_eval(gsa_ctx* ctx, void* stream, int32_t n, int32_t classes
 int gsa_profile_enable(gsa_ctx* ctx, int32_t on);
 /* Synchronises the recorded events and returns the number of distinct kernel labels. */
 int gsa_profile_collect(gsa_ctx* ctx);
-/* Label i: name, accumulated milliseconds, launch count, algorithmic flops and bytes summed
- * over those launches.  Returns 0, or GSA_ERR_INVALID when i is out of range. */
+/* Label i: name, accumulated milliseconds, launch count, and summed over those launches: the FLOP the kernel executes,
+ * its algorithmic bytes, and the FLOP of the same layers in the reference's formulation (2*MACs of the direct
+ * convolution, SURVEY.md section 8d -- larger than `flops` where the kernel uses the sub-pixel or the Winograd form).
+ * Any out pointer may be NULL.  Returns 0, or GSA_ERR_INVALID when i is out of range. */
 int gsa_profile_entry(gsa_ctx* ctx, int32_t i, const char** name, double* ms, int64_t* launches,
-                      double* flops, double* bytes);
+                      double* flops, double* bytes, double* alg_flops);
 int gsa_profile_reset(gsa_ctx* ctx);
 
 /* Library build string (version, arch). */

@@ -581,41 +581,55 @@ static inline float bf16r(float f) {
 /* 3x3 conv, pad 1, NHWC.  in: [Hs][Ws][Cin] (already affine-applied); when up!=0 the
  * logical input is the nearest-x2 upsample of `in` (UpSampling, reference :308-315).
  * out: raw accumulators [H][W][Cout], H = Hs<<up. */
+/* K split (static rule, by layer shape only): a direct 3x3 convolution over >= 64 input channels (a multiple of 64) whose
+ * output is <= 8 px, or <= 32 px with at most 32 output channels (too few tiles to fill the chip otherwise), is
+ * accumulated as FOUR independent chains, chain q over the q-th contiguous quarter of the 16-channel blocks, combined as
+ * (s0 + s1) + (s2 + s3).  On the GPU the four waves of a workgroup each take one quarter: the 512-channel layers at
+ * 4^2-32^2 were ONE dependent chain of 1152 MFMAs behind 32 load -> LDS -> barrier rounds before. */
+static int use_ksplit(int Cin, int H, int Cout) { return Cin >= 64 && Cin % 64 == 0 && (H <= 8 || (H <= 32 && Cout <= 32)); }
+
 static void conv3x3(const float* in, int Hs, int Ws, int Cin, int up, const float* Wp, int Cout, float* out, int bf, int perm) {
     const int H = Hs << up, W = Ws << up;
+    const int nblk = Cin / CB;
+    const int nq = (perm && use_ksplit(Cin, H, Cout)) ? 4 : 1, bq = nblk / nq;      /* perm = 0: the final conv (vector ALU): one chain */
 #pragma omp parallel for schedule(dynamic, 1)
     for (int y = 0; y < H; ++y)
         for (int x0 = 0; x0 < W; x0 += PX)
             for (int o0 = 0; o0 < Cout; o0 += OC) {
                 const int on = Cout - o0 < OC ? Cout - o0 : OC;
-                float acc[PX][OC];
-                for (int p = 0; p < PX; ++p)
-                    for (int o = 0; o < OC; ++o) acc[p][o] = 0.0f;
-                for (int cb = 0; cb < Cin / CB; ++cb)
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int yy = y + ky - 1;
-                        if (yy < 0 || yy >= H) continue;
-                        for (int kx = 0; kx < 3; ++kx)
-                            for (int kk = 0; kk < CB; ++kk) {
-                                const int ci = perm ? CPERM(kk) : kk;     /* perm = 0: the final conv (vector ALU, ascending channels) */
-                                const float* wsrc = Wp + (((size_t)cb * 9 + ky * 3 + kx) * CB + ci) * Cout + o0;
-                                float wrow[OC];
-                                for (int o = 0; o < on; ++o) wrow[o] = OPND(wsrc[o]);
-                                for (int o = on; o < OC; ++o) wrow[o] = 0.0f;
-                                for (int p = 0; p < PX; ++p) {
-                                    const int xx = x0 + p + kx - 1;
-                                    if (xx < 0 || xx >= W) continue;
-                                    const float a = OPND(in[((size_t)(yy >> up) * Ws + (xx >> up)) * Cin + cb * CB + ci]);
-                                    if (on == OC) {
-                                        for (int o = 0; o < OC; ++o) acc[p][o] = fmaf(a, wrow[o], acc[p][o]);
-                                    } else {
-                                        for (int o = 0; o < on; ++o) acc[p][o] = fmaf(a, wrow[o], acc[p][o]);
+                float part[4][PX][OC];
+                for (int q = 0; q < nq; ++q) {
+                    float (*acc)[OC] = part[q];
+                    for (int p = 0; p < PX; ++p)
+                        for (int o = 0; o < OC; ++o) acc[p][o] = 0.0f;
+                    for (int cb = q * bq; cb < (q + 1) * bq; ++cb)
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const int yy = y + ky - 1;
+                            if (yy < 0 || yy >= H) continue;
+                            for (int kx = 0; kx < 3; ++kx)
+                                for (int kk = 0; kk < CB; ++kk) {
+                                    const int ci = perm ? CPERM(kk) : kk;     /* perm = 0: ascending channels */
+                                    const float* wsrc = Wp + (((size_t)cb * 9 + ky * 3 + kx) * CB + ci) * Cout + o0;
+                                    float wrow[OC];
+                                    for (int o = 0; o < on; ++o) wrow[o] = OPND(wsrc[o]);
+                                    for (int o = on; o < OC; ++o) wrow[o] = 0.0f;
+                                    for (int p = 0; p < PX; ++p) {
+                                        const int xx = x0 + p + kx - 1;
+                                        if (xx < 0 || xx >= W) continue;
+                                        const float a = OPND(in[((size_t)(yy >> up) * Ws + (xx >> up)) * Cin + cb * CB + ci]);
+                                        if (on == OC) {
+                                            for (int o = 0; o < OC; ++o) acc[p][o] = fmaf(a, wrow[o], acc[p][o]);
+                                        } else {
+                                            for (int o = 0; o < on; ++o) acc[p][o] = fmaf(a, wrow[o], acc[p][o]);
+                                        }
                                     }
                                 }
-                            }
-                    }
+                        }
+                }
                 for (int p = 0; p < PX; ++p)
-                    for (int o = 0; o < on; ++o) out[((size_t)y * W + x0 + p) * Cout + o0 + o] = acc[p][o];
+                    for (int o = 0; o < on; ++o)
+                        out[((size_t)y * W + x0 + p) * Cout + o0 + o] =
+                            nq == 4 ? (part[0][p][o] + part[1][p][o]) + (part[2][p][o] + part[3][p][o]) : part[0][p][o];
             }
 }
 
