@@ -15,6 +15,9 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work of a
  *    call is enqueued on it in order;
  *  - one context per (device, host thread); contexts are not thread-safe;
+ *  - instance-norm statistics are order-independent 64-bit fixed-point sums (2^-28 for sums, 2^-20 for squares, per aligned
+ *    quad of 4 pixels): exact and deterministic while |x| < 2.3e4 per value and rms(x) < 2.9e3 over a 1024^2 plane (mean |x| <
+ *    3.2e4); beyond that the sums wrap silently.  Post-LeakyReLU StyleGAN-v1 activations are O(1..100);
  *  - tensors crossing the boundary use the reference's layouts: fp32 NCHW activations,
  *    OIHW conv weights, (N,H,W,3) u8 RGB images, (N,H,W) u8 masks.
  *
