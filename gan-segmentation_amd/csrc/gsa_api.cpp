@@ -432,7 +432,8 @@ struct Launch {
         }
         c->prof_entries[entry].flops += flops;
         c->prof_entries[entry].alg_flops += alg < 0 ? flops : alg;
-        c->prof_entries[entry].bytes += bytes;
+        // bf16 mode: the activation tensors are 2 bytes per element (the fp32 noise planes and the parameters are a few per cent)
+        c->prof_entries[entry].bytes += (c->bf16 && layer && strncmp(layer, "g.mapping", 9) && strncmp(layer, "g.styles", 8) && !strstr(layer, "finalize")) ? 0.5 * bytes : bytes;
         c->prof_entries[entry].launches += 1;
         auto get = [&]() {
             hipEvent_t e = nullptr;
@@ -904,7 +905,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
             if (k == 0) {
                 PostParams pp{};
                 pp.noise = nz; pp.nscale = B.nscale[0]; pp.nbias = B.nbias[0];
-                pp.out = c->x1; pp.partials = c->partials; pp.H = R; pp.W = R; pp.C = C;
+                pp.out = c->x1; pp.partials = c->partials; pp.H = R; pp.W = R; pp.C = C; pp.bf16 = c->bf16;
                 if (!B.has_conv1) {
                     pp.src = c->constant; pp.src_per_sample = 0; pp.blur = nullptr;
                 } else {
@@ -957,14 +958,14 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
         if (feats && feats[l]) {
             snprintf(layer, sizeof layer, "g.%d.export", R);
             Launch lp(c, s, "export_nchw_kernel", layer, 0.0, 8.0 * px * C);
-            HIP_TRY(launch_export_nchw(c->x2[l], c->aff2[l], feats[l], n, R, R, C, s));
+            HIP_TRY(launch_export_nchw(c->x2[l], c->aff2[l], feats[l], n, R, R, C, c->bf16, s));
         }
     }
     if (rgb || img) {
         const int l = nlev - 1, R = c->blk[l].R, C = c->blk[l].C, nc = c->gc.channels;
         const double px = N * R * R;
         Launch lp(c, s, C <= 16 ? "torgb_direct_kernel" : "torgb_kernel", "g.torgb", 2.0 * px * C * nc, px * (4.0 * C + (rgb ? 4.0 * nc : 0) + (img ? nc : 0)));
-        HIP_TRY(launch_torgb(c->x2[l], c->aff2[l], c->rgb_w, c->rgb_b, rgb, img, n, R, R, C, nc, s));
+        HIP_TRY(launch_torgb(c->x2[l], c->aff2[l], c->rgb_w, c->rgb_b, rgb, img, n, R, R, C, nc, c->bf16, s));
     }
     return GSA_OK;
 }
@@ -1032,7 +1033,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
         } else {
             snprintf(layer, sizeof layer, "d.final_%d", i);
             Launch lp(c, s, "final_conv_kernel", layer, 2.0 * px * d.cs * d.in_c * 9, px * (4.0 * d.in_c + (logits ? 4.0 * d.cs : 0) + (mask ? 1 : 0)));
-            HIP_TRY(launch_final_conv(i > s0 ? c->prev[i - 1] : nullptr, i > s0 ? d.F : 0, c->cvt[i], d.F, d.f_w, d.f_b, logits, mask, n, R, R, d.cs, s));
+            HIP_TRY(launch_final_conv(i > s0 ? c->prev[i - 1] : nullptr, i > s0 ? d.F : 0, c->cvt[i], d.F, d.f_w, d.f_b, logits, mask, n, R, R, d.cs, c->bf16, s));
         }
     }
     return GSA_OK;
@@ -1069,7 +1070,7 @@ int gsa_decoder_forward(gsa_ctx* c, void* stream, int32_t n, const float* const*
         if (!feats[i]) return fail(c, GSA_ERR_INVALID, "feature %d is null", i);
         const int R = 4 << i;
         Launch lp(c, s, "import_nhwc_kernel", "d.import", 0.0, 8.0 * n * R * R * c->dl[i].I);
-        HIP_TRY(launch_import_nhwc(feats[i], c->din[i], n, R, R, c->dl[i].I, s));
+        HIP_TRY(launch_import_nhwc(feats[i], c->din[i], n, R, R, c->dl[i].I, c->bf16, s));
         fsrc[i] = c->din[i];
     }
     return run_decoder(c, s, n, fsrc, nullptr, logits, mask);

@@ -56,6 +56,7 @@ struct PostParams {
     const float* noise; const float* nscale; const float* nbias;
     float* out; StatPart* partials; int prow;
     int H, W, C;
+    int bf16;              // 1: the per-sample source and the output are bf16 tensors (bf16 mode)
 };
 
 struct FinalizeParams {
@@ -81,11 +82,11 @@ hipError_t launch_dense(const float* x, const float* WT, const float* b, float* 
 hipError_t launch_styles(const float* w, const float* avg, const float* psi, const float* WT, const float* b,
                          const int* col_layer, float* styles, int n, int K, int J, hipStream_t s);
 hipError_t launch_torgb(const float* x, const Aff* aff, const float* w, const float* b, float* rgb,
-                        uint8_t* img, int n, int H, int W, int C, int nc, hipStream_t s);
-hipError_t launch_export_nchw(const float* x, const Aff* aff, float* out, int n, int H, int W, int C, hipStream_t s);
-hipError_t launch_import_nhwc(const float* in, float* out, int n, int H, int W, int C, hipStream_t s);
+                        uint8_t* img, int n, int H, int W, int C, int nc, int bf16, hipStream_t s);
+hipError_t launch_export_nchw(const float* x, const Aff* aff, float* out, int n, int H, int W, int C, int bf16, hipStream_t s);
+hipError_t launch_import_nhwc(const float* in, float* out, int n, int H, int W, int C, int bf16, hipStream_t s);
 hipError_t launch_final_conv(const float* src0, int C0, const float* src1, int C1, const float* wpk,
-                             const float* bias, float* logits, uint8_t* mask, int n, int H, int W, int ncls,
+                             const float* bias, float* logits, uint8_t* mask, int n, int H, int W, int ncls, int bf16,
                              hipStream_t s);
 
 // geometry the launchers pick (weights are packed per 16 output channels, so it is free to vary)

@@ -131,13 +131,52 @@ struct TilePixel {   // one staged pixel of this thread
     int lds;         // float offset in the LDS image, or -1: this thread stages nothing
 };
 
+// ---- activation tensors: fp32, or (bf16 mode, BF = true) bf16 in the same NHWC order ------------------------------------
+// In bf16 mode every activation tensor that lives in HBM is bf16 (round 2; round 1 kept fp32 there and only rounded the MFMA
+// operands): half the bytes of kernels that are HBM-bound in that mode.  Pointers stay typed `float*` in the parameter
+// structs; the element index is the same in both modes, the element size is not.  Arithmetic stays fp32: a consumer widens
+// (exact), applies AdaIN in fp32 and rounds to bf16 (RNE) once more for the MFMA operand; statistics are taken from the fp32
+// values before the producer rounds them for storage.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <bool BF>
+__device__ __forceinline__ f32x4 act_load4(const float* base, size_t idx) {      // 4 consecutive channels at element idx
+    if constexpr (BF) {
+        const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        return f32x4{bf16_lo(r[0]), bf16_hi(r[0]), bf16_lo(r[1]), bf16_hi(r[1])};
+    } else {
+        return *reinterpret_cast<const f32x4*>(base + idx);
+    }
+}
+
+template <bool BF>
+__device__ __forceinline__ void act_store4(float* base, size_t idx, const f32x4& v) {
+    if constexpr (BF) {
+        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + idx) =
+            u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2)),
+                  __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2))};
+    } else {
+        *reinterpret_cast<f32x4*>(base + idx) = v;
+    }
+}
+
 // Unconditional loads (padding / idle threads read pixel 0 and discard it): no branch sits
 // between a global load and its use, so the compiler keeps every load of a block in flight.
+// BF: the 16 channels of the block are 32 bytes; they travel as raw bits in v[0], v[1].
+template <bool BF = false>
 __device__ __forceinline__ void load_pixel(f32x4 (&v)[4], const float* src, int Cs, int coff, const TilePixel& tp) {
     const int pix = tp.pix >= 0 ? tp.pix : 0;
-    const f32x4* ptr = reinterpret_cast<const f32x4*>(src + (size_t)pix * Cs + coff);
+    if constexpr (BF) {
+        const f32x4* ptr = reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)pix * Cs + coff);
+        v[0] = ptr[0]; v[1] = ptr[1];
+    } else {
+        const f32x4* ptr = reinterpret_cast<const f32x4*>(src + (size_t)pix * Cs + coff);
 #pragma unroll
-    for (int cg = 0; cg < 4; ++cg) v[cg] = ptr[cg];
+        for (int cg = 0; cg < 4; ++cg) v[cg] = ptr[cg];
+    }
 }
 
 // AdaIN on the fly (zero padding stays zero), then the transposed 4x4 store.
@@ -154,8 +193,26 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 template <bool HAS_AFF, bool BF = false, bool MASK = true>
 __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const float4* saff, const TilePixel& tp) {
     const bool inside = !MASK || tp.pix >= 0;
-    float f[16] = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3],
-                   v[2][0], v[2][1], v[2][2], v[2][3], v[3][0], v[3][1], v[3][2], v[3][3]};
+    if constexpr (BF && !HAS_AFF) {      // bf16 tensor, no AdaIN: the LDS image IS the tensor's 32 bytes (zero outside the image)
+        if (tp.lds >= 0) {
+            f32x4* dst = reinterpret_cast<f32x4*>(sA + tp.lds);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            dst[0] = inside ? v[0] : z;
+            dst[1] = inside ? v[1] : z;
+        }
+        return;
+    }
+    float f[16];
+    if constexpr (BF) {                  // widen the 16 bf16 channels (exact)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned u = __float_as_uint(v[k >> 2][k & 3]);
+            f[2 * k] = bf16_lo(u); f[2 * k + 1] = bf16_hi(u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f[k] = v[k >> 2][k & 3];
+    }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         float t = f[c];
@@ -380,7 +437,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
         const int Cs = first ? p.C0 : p.C1;
         const int coff = (first ? cb : cb - nblk0) * 16;
 #pragma unroll
-        for (int it = 0; it < AIT; ++it) load_pixel(ra[it], src, Cs, coff, tp[it]);
+        for (int it = 0; it < AIT; ++it) load_pixel<BF>(ra[it], src, Cs, coff, tp[it]);
         if (!wres) {
             const float* wblk = p.wpk + ((size_t)t.g * Q * nblk + cb) * SEG;      // wave-uniform
 #pragma unroll
@@ -480,8 +537,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
                     // channels [0, res_c0) live in resid, the rest in resid1; a 16-channel group never straddles the split
                     const int cch = tc.g * COUT_T + (wn * NT + nt) * 16;
                     const bool second = p.resid1 != nullptr && cch >= p.res_c0;
-                    const float* rsrc = (second ? p.resid1 : p.resid) + rpix * (second ? res_cs1 : res_cs0) + (second ? cch - p.res_c0 : cch);
-                    rr[mt][nt] = *reinterpret_cast<const f32x4*>(rsrc + (second ? lane_res1 : lane_res0));
+                    rr[mt][nt] = act_load4<BF>(second ? p.resid1 : p.resid, rpix * (second ? res_cs1 : res_cs0) + (second ? cch - p.res_c0 : cch) +
+                                                                             (second ? lane_res1 : lane_res0));
                 }
             }
         }
@@ -551,11 +608,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 #ifdef GSA_DBG_HOOKS
                     if (!(p.dbg & 4))      // timing-only: no epilogue stores
 #endif
-                    *reinterpret_cast<f32x4*>(p.out + ubase + lane_out) = vt;
+                    act_store4<BF>(p.out, ubase + lane_out, vt);
                     if (SC) {
-                        *reinterpret_cast<f32x4*>(p.out_sc + ubase + lane_out) =
+                        act_store4<BF>(p.out_sc, ubase + lane_out,
                             quad_transpose(accs[mt][nt][0] + scb[nt], accs[mt][nt][1] + scb[nt], accs[mt][nt][2] + scb[nt],
-                                           accs[mt][nt][3] + scb[nt], xj);
+                                           accs[mt][nt][3] + scb[nt], xj));
                     }
                     acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (SC) accs[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -863,7 +920,7 @@ __global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
     const float* wgrp = p.wpk + (size_t)g * nblk * SEG;
     auto load_item = [&](int it) {                    // blocks q*nq + it, q = 0..3
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load_pixel(ra[q], p.src0, p.C0, (q * nq + it) * 16, tp);
+        for (int q = 0; q < 4; ++q) load_pixel<BF>(ra[q], p.src0, p.C0, (q * nq + it) * 16, tp);
 #pragma unroll
         for (int j = 0; j < BIT; ++j) {
             const int i = min(tid + j * NTHR, NB4 - 1);
@@ -974,12 +1031,11 @@ __global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
         const int cch = g * 16;
         const bool second = p.resid1 != nullptr && cch >= p.res_c0;
         const int rcs = second ? p.Cout - p.res_c0 : (p.resid1 ? p.res_c0 : p.Cout);
-        const float* rsrc = (second ? p.resid1 : p.resid) + rpix * rcs + (second ? cch - p.res_c0 : cch) + cq4;
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(rsrc);
+        const f32x4 rr = act_load4<BF>((second ? p.resid1 : p.resid), rpix * rcs + (second ? cch - p.res_c0 : cch) + cq4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) vt[r] = rr[r] + vt[r];
     }
-    *reinterpret_cast<f32x4*>(p.out + ((size_t)(n * p.H + y) * p.W + xb + xj) * p.Cout + g * 16 + cq4) = vt;
+    act_store4<BF>(p.out, ((size_t)(n * p.H + y) * p.W + xb + xj) * p.Cout + g * 16 + cq4, vt);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1403,7 +1459,7 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
         const float* src = first ? p.src0 : p.src1;
         const int Cs = first ? p.C0 : p.C1;
         const int coff = (first ? cb : cb - nblk0) * 16;
-        load_pixel(ra, src, Cs, coff, tp);
+        load_pixel<BF>(ra, src, Cs, coff, tp);
 #pragma unroll
         for (int j = 0; j < BIT; ++j) {
             const int i = min(tid + j * 256, NB4 - 1);
@@ -1541,13 +1597,13 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 #ifdef GSA_DBG_HOOKS
             if (!(p.dbg & 4))
 #endif
-            *reinterpret_cast<f32x4*>(p.out + ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + cot) = vt;
+            act_store4<BF>(p.out, ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + cot, vt);
         }
         if (SC) {
             const int iy = y0 / 2 + (wave >> 1) * 4 + (lane >> 4);
             const int ix = x0 / 2 + (wave & 1) * 4 + xj;
-            *reinterpret_cast<f32x4*>(p.out_sc + ((size_t)(n * p.Hs + iy) * p.Ws + ix) * p.Cout + cot) =
-                quad_transpose(accs[nt][0] + scb[nt], accs[nt][1] + scb[nt], accs[nt][2] + scb[nt], accs[nt][3] + scb[nt], xj);
+            act_store4<BF>(p.out_sc, ((size_t)(n * p.Hs + iy) * p.Ws + ix) * p.Cout + cot,
+                quad_transpose(accs[nt][0] + scb[nt], accs[nt][1] + scb[nt], accs[nt][2] + scb[nt], accs[nt][3] + scb[nt], xj));
         }
     }
 }
@@ -1688,7 +1744,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
         for (int kb = 0; kb < KB; ++kb) {
             const int cb = ci * KB + kb;
             const bool first = cb < nblk0;
-            load_pixel(ra[kb], first ? p.src0 : p.src1, first ? p.C0 : p.C1, (first ? cb : cb - nblk0) * 16, tp);
+            load_pixel<BF>(ra[kb], first ? p.src0 : p.src1, first ? p.C0 : p.C1, (first ? cb : cb - nblk0) * 16, tp);
             if (has_aff && first) raff[kb] = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0 + cb * 16)[tid & 15];
         }
     };
@@ -1793,13 +1849,13 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
                 }
                 const f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
                 const size_t ubase = ((size_t)(t.n * p.H + t.y0 + 8 * (mt >> 1) + py) * p.W + t.x0 + 8 * (mt & 1) + px) * p.Cout + g * 16 * NT + nt * 16;
-                *reinterpret_cast<f32x4*>(p.out + ubase + lane_out) = vt;
+                act_store4<BF>(p.out, ubase + lane_out, vt);
                 acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (SC) {
                 const size_t ubase = ((size_t)(t.n * p.Hs + (t.y0 >> 1) + (wave >> 1) * 4) * p.Ws + (t.x0 >> 1) + (wave & 1) * 4) * p.Cout + g * 16 * NT + nt * 16;
-                *reinterpret_cast<f32x4*>(p.out_sc + ubase + lane_sc) =
-                    quad_transpose(accs[nt][0] + scb[nt], accs[nt][1] + scb[nt], accs[nt][2] + scb[nt], accs[nt][3] + scb[nt], xj);
+                act_store4<BF>(p.out_sc, ubase + lane_sc,
+                    quad_transpose(accs[nt][0] + scb[nt], accs[nt][1] + scb[nt], accs[nt][2] + scb[nt], accs[nt][3] + scb[nt], xj));
                 accs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -1850,6 +1906,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
 // ------------------------------------------------------------------------------------------
 // Blur (depthwise 3x3, zero pad) -> AddNoise -> Bias -> LeakyReLU -> statistics.
 // One thread = one aligned quad of 4 consecutive x for 4 consecutive channels.
+template <bool BF>
 __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sstat[];   // [2][C]
     const int n = blockIdx.y;
@@ -1866,7 +1923,8 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
         const int cq = idx % C4, t = idx / C4;
         const int xq = (t / bh) % W4, y = (t / (bh * W4)) * bh + t % bh;
         const int c = cq * 4, x0 = xq * 4;
-        const float* src = p.src + (p.src_per_sample ? (size_t)n * p.H * p.W * p.C : 0);
+        // per-sample source = an activation tensor (bf16 in bf16 mode); the broadcast constant tensor is an fp32 parameter
+        const size_t sbase = p.src_per_sample ? (size_t)n * p.H * p.W * p.C : 0;
         float v[4][4];   // [x][channel]
         if (p.blur) {
             float wk[4][9];
@@ -1890,7 +1948,8 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
                 for (int k = 0; k < 6; ++k) {
                     const int xx = x0 - 1 + k;
                     const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
-                    row[ky][k] = *reinterpret_cast<const float4*>(src + ((size_t)yc * p.W + xc) * p.C + c);
+                    const f32x4 ld = act_load4<BF>(p.src, sbase + ((size_t)yc * p.W + xc) * p.C + c);
+                    row[ky][k] = make_float4(ld[0], ld[1], ld[2], ld[3]);
                     if (!(vy && xx >= 0 && xx < p.W)) row[ky][k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
@@ -1909,7 +1968,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float4 t = *reinterpret_cast<const float4*>(src + ((size_t)y * p.W + x0 + r) * p.C + c);
+                const float4 t = *reinterpret_cast<const float4*>(p.src + sbase + ((size_t)y * p.W + x0 + r) * p.C + c);      // no blur: the fp32 constant tensor
                 v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
             }
         }
@@ -1925,8 +1984,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
                 const float t = sfv[j] * nzv[r];
                 v[r][j] = lrelu((v[r][j] + t) + nbv[j]);
             }
-            *reinterpret_cast<float4*>(p.out + (((size_t)n * p.H + y) * p.W + x0 + r) * p.C + c) =
-                make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+            act_store4<BF>(p.out, (((size_t)n * p.H + y) * p.W + x0 + r) * p.C + c, f32x4{v[r][0], v[r][1], v[r][2], v[r][3]});
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1948,7 +2006,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
 // new row instead of 18 per output row: the first form was bound by its load instructions, 3.5-4.1 TB/s), the loads of row
 // r+2 are in flight while row r is computed, and the statistics of the RPT rows stay in registers until the end.
 // Same arithmetic in the same order per output (9-tap fmaf chain ky, kx ascending; zero padding = zeroed values).
-template <int RPT>
+template <int RPT, bool BF>
 __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sstat[];   // [2][C]
     const int n = blockIdx.y;
@@ -1961,7 +2019,7 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
         const int cq = idx % C4, t = idx / C4;
         const int xq = t % W4, y0 = (t / W4) * RPT;
         const int c = cq * 4, x0 = xq * 4;
-        const float* src = p.src + (size_t)n * p.H * p.W * p.C + c;
+        const size_t sbase = (size_t)n * p.H * p.W * p.C + c;
         float wk[4][9];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -1981,10 +2039,11 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
         auto load_row = [&](float4 (&row)[6], int yy) {      // unconditional loads (clamped), padding = zeroed values
             const bool vy = yy >= 0 && yy < p.H;
             const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
-            const float* rp = src + (size_t)yc * p.W * p.C;
+            const size_t rp = sbase + (size_t)yc * p.W * p.C;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                row[k] = *reinterpret_cast<const float4*>(rp + xoff[k]);
+                const f32x4 ld = act_load4<BF>(p.src, rp + xoff[k]);
+                row[k] = make_float4(ld[0], ld[1], ld[2], ld[3]);
                 if (!(vy && xin[k])) row[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
@@ -2023,8 +2082,7 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
                     const float tn = sfv[j] * nzv[q];
                     v[q][j] = lrelu((v[q][j] + tn) + nbv[j]);
                 }
-                *reinterpret_cast<float4*>(p.out + (((size_t)n * p.H + y) * p.W + x0 + q) * p.C + c) =
-                    make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+                act_store4<BF>(p.out, (((size_t)n * p.H + y) * p.W + x0 + q) * p.C + c, f32x4{v[q][0], v[q][1], v[q][2], v[q][3]});
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -2141,11 +2199,10 @@ __global__ void pixelnorm_kernel(const float* z, float* out, int n, int L) {
 // LDS, so the 512-step chain costs ~2 us instead of 512 dependent global-load round trips.
 // JB = output columns per workgroup: 64 for the wide style affines, 16 for the 512-wide mapping layers (32 workgroups
 // instead of 8: the eight layers are a serial latency chain at the head of every step)
-template <bool STYLE, int JB>
+template <bool STYLE, int JB, int KC>      // KC = K rows per LDS pass
 __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const float* WT, const float* b, float* y,
                                                         int n, int K, int J, int act, const float* avg,
                                                         const float* psi, const int* col_layer) {
-    constexpr int KC = 128;                         // K rows per LDS pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int G = 256 / JB, SPT = 16 / G;       // sample groups, samples per thread (16 samples per pass)
     float* sW = smem;                               // [KC][JB]
@@ -2210,26 +2267,26 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const fl
 // ------------------------------------------------------------------------------------------
 // toRGB (1x1 conv + bias) and the uint8 image of _transform_gan_back.
 // One thread per pixel reading its own channels: right for C <= 16 (one 64-byte line per pixel).
-template <int CT>      // CT = 16: the channel count is known, all four 16-byte loads of a pixel are issued up front
+template <int CT, bool BF>      // CT = 16: the channel count is known, all four 16-byte loads of a pixel are issued up front
 __global__ __launch_bounds__(256) void torgb_direct_kernel(const float* x, const Aff* aff, const float* w, const float* b,
                                                     float* rgb, uint8_t* img, int HW, int Crt, int nc) {
     const int C = CT > 0 ? CT : Crt;
     const int n = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= HW) return;
-    const float* px = x + ((size_t)n * HW + pix) * C;
+    const size_t px = ((size_t)n * HW + pix) * C;
     const Aff* a = aff + (size_t)n * C;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    float4 pre[CT > 0 ? CT / 4 : 1];
+    f32x4 pre[CT > 0 ? CT / 4 : 1];
     if (CT > 0) {
 #pragma unroll
-        for (int k = 0; k < CT / 4; ++k) pre[k] = *reinterpret_cast<const float4*>(px + 4 * k);
+        for (int k = 0; k < CT / 4; ++k) pre[k] = act_load4<BF>(x, px + 4 * k);
     }
 #pragma unroll
     for (int c = 0; c < C; c += 4) {
-        const float4 v = CT > 0 ? pre[c / 4] : *reinterpret_cast<const float4*>(px + c);
-        const float f[4] = {fmaf(v.x - a[c].mean, a[c].A, a[c].B), fmaf(v.y - a[c + 1].mean, a[c + 1].A, a[c + 1].B),
-                            fmaf(v.z - a[c + 2].mean, a[c + 2].A, a[c + 2].B), fmaf(v.w - a[c + 3].mean, a[c + 3].A, a[c + 3].B)};
+        const f32x4 v = CT > 0 ? pre[c / 4] : act_load4<BF>(x, px + c);
+        const float f[4] = {fmaf(v[0] - a[c].mean, a[c].A, a[c].B), fmaf(v[1] - a[c + 1].mean, a[c + 1].A, a[c + 1].B),
+                            fmaf(v[2] - a[c + 2].mean, a[c + 2].A, a[c + 2].B), fmaf(v[3] - a[c + 3].mean, a[c + 3].A, a[c + 3].B)};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -2253,6 +2310,7 @@ __global__ __launch_bounds__(256) void torgb_direct_kernel(const float* x, const
 // and each thread then walks ITS pixel's channels in order -- the canonical k-ordered fmaf chain -- out of LDS.
 // (One thread reading its own pixel straight from HBM touched 64 different cache lines per load instruction and
 // fetched the tensor 6.4 times at C = 32.)
+template <bool BF>
 __global__ __launch_bounds__(256) void torgb_kernel(const float* x, const Aff* aff, const float* w, const float* b,
                                                     float* rgb, uint8_t* img, int HW, int C, int nc) {
     constexpr int CH = 32, LS = CH + 4;
@@ -2268,8 +2326,7 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* x, const Aff* a
         if (c0) __syncthreads();
         for (int i = tid; i < npx * q4; i += 256) {
             const int pl = i / q4, cq = i - pl * q4;
-            *reinterpret_cast<float4*>(&tile[pl * LS + cq * 4]) =
-                *reinterpret_cast<const float4*>(x + ((size_t)n * HW + p0 + pl) * C + c0 + cq * 4);
+            *reinterpret_cast<f32x4*>(&tile[pl * LS + cq * 4]) = act_load4<BF>(x, ((size_t)n * HW + p0 + pl) * C + c0 + cq * 4);
         }
         __syncthreads();
         if (tid < npx) {
@@ -2300,14 +2357,15 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* x, const Aff* a
 }
 
 // feature export: NHWC (+AdaIN) -> NCHW fp32, the layout the reference returns
+template <bool BF>
 __global__ __launch_bounds__(256) void export_nchw_kernel(const float* x, const Aff* aff, float* out, int HW, int C) {
     __shared__ float tile[64][17];
     const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 16;
     {   // read 64 pixels x 16 channels, channel fastest
         const int pl = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 4;
         if (p0 + pl < HW) {
-            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * HW + p0 + pl) * C + c0 + cq);
-            float f[4] = {v.x, v.y, v.z, v.w};
+            const f32x4 v = act_load4<BF>(x, ((size_t)n * HW + p0 + pl) * C + c0 + cq);
+            float f[4] = {v[0], v[1], v[2], v[3]};
             if (aff) {
                 const Aff* a = aff + (size_t)n * C + c0 + cq;
 #pragma unroll
@@ -2330,6 +2388,7 @@ __global__ __launch_bounds__(256) void export_nchw_kernel(const float* x, const 
 }
 
 // feature import: NCHW fp32 -> NHWC
+template <bool BF>
 __global__ __launch_bounds__(256) void import_nhwc_kernel(const float* in, float* out, int HW, int C) {
     __shared__ float tile[64][17];
     const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 16;
@@ -2346,8 +2405,7 @@ __global__ __launch_bounds__(256) void import_nhwc_kernel(const float* in, float
     {
         const int pl = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 4;
         if (p0 + pl < HW)
-            *reinterpret_cast<float4*>(out + ((size_t)n * HW + p0 + pl) * C + c0 + cq) =
-                make_float4(tile[pl][cq], tile[pl][cq + 1], tile[pl][cq + 2], tile[pl][cq + 3]);
+            act_store4<BF>(out, ((size_t)n * HW + p0 + pl) * C + c0 + cq, f32x4{tile[pl][cq], tile[pl][cq + 1], tile[pl][cq + 2], tile[pl][cq + 3]});
     }
 }
 
@@ -2355,7 +2413,7 @@ __global__ __launch_bounds__(256) void import_nhwc_kernel(const float* in, float
 // Final conv3x3 (in_c -> NCLS classes) + bias + argmax (first maximum wins).  NCLS is tiny
 // (2 in the reference), so the contraction runs on the vector ALU: one thread per pixel,
 // input tile staged in LDS, weights through uniform (scalar) loads.
-template <int NCLS>
+template <int NCLS, bool BF>
 __global__ __launch_bounds__(256) void final_conv_kernel(const float* src0, int C0, const float* src1, int C1,
                                                          const float* wpk, const float* bias, float* logits,
                                                          uint8_t* mask, int H, int W, int tiles_x) {
@@ -2384,10 +2442,11 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* src0, int 
             const int gy = y0 - 1 + sy, gx = x0 - 1 + sx;
             const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            const float4* ptr = reinterpret_cast<const float4*>(src + ((size_t)(n * H + cy) * W + cx) * Cs + coff);
+            const size_t eidx = ((size_t)(n * H + cy) * W + cx) * Cs + coff;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                pre[it][k] = ptr[k];
+                const f32x4 ld = act_load4<BF>(src, eidx + 4 * k);
+                pre[it][k] = make_float4(ld[0], ld[1], ld[2], ld[3]);
                 if (!inside) pre[it][k] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -3032,10 +3091,13 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
     q.prow = post_rows_used(p);
     dim3 grid(q.prow, n);
     const size_t lds = sizeof(unsigned long long) * 2 * p.C;
-    if (rpt == 8) hipLaunchKernelGGL(post_rows_kernel<8>, grid, dim3(256), lds, s, q);
-    else if (rpt == 4) hipLaunchKernelGGL(post_rows_kernel<4>, grid, dim3(256), lds, s, q);
-    else if (rpt == 2) hipLaunchKernelGGL(post_rows_kernel<2>, grid, dim3(256), lds, s, q);
-    else hipLaunchKernelGGL(post_kernel, grid, dim3(256), lds, s, q);
+#define GSA_POST(BF) \
+    if (rpt == 8) hipLaunchKernelGGL((post_rows_kernel<8, BF>), grid, dim3(256), lds, s, q); \
+    else if (rpt == 4) hipLaunchKernelGGL((post_rows_kernel<4, BF>), grid, dim3(256), lds, s, q); \
+    else if (rpt == 2) hipLaunchKernelGGL((post_rows_kernel<2, BF>), grid, dim3(256), lds, s, q); \
+    else hipLaunchKernelGGL(post_kernel<BF>, grid, dim3(256), lds, s, q);
+    if (p.bf16) { GSA_POST(true) } else { GSA_POST(false) }
+#undef GSA_POST
     return hipGetLastError();
 }
 
@@ -3055,9 +3117,11 @@ hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_
 }
 
 hipError_t launch_dense(const float* x, const float* WT, const float* b, float* y, int n, int K, int J, int act, hipStream_t s) {
-    if (K % 128 || J % 4) return hipErrorInvalidValue;
-    const size_t lds = sizeof(float) * (128 * 16 + 16 * 128 + 128);
-    hipLaunchKernelGGL((dense_lds_kernel<false, 16>), dim3((J + 15) / 16), dim3(256), lds, s, x, WT, b, y, n, K, J, act,
+    // 256 K rows per pass: the eight mapping layers are a serial chain at the head of every step, each pass a global load ->
+    // LDS -> barrier -> 256-step fmaf chain round trip (two passes per layer instead of four: 11.3 -> ~7 us per layer)
+    if (K % 256 || J % 4) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * (256 * 16 + 16 * 256 + 256);
+    hipLaunchKernelGGL((dense_lds_kernel<false, 16, 256>), dim3((J + 15) / 16), dim3(256), lds, s, x, WT, b, y, n, K, J, act,
                        (const float*)nullptr, (const float*)nullptr, (const int*)nullptr);
     return hipGetLastError();
 }
@@ -3066,53 +3130,61 @@ hipError_t launch_styles(const float* w, const float* avg, const float* psi, con
                          const int* col_layer, float* styles, int n, int K, int J, hipStream_t s) {
     if (K % 128 || J % 4) return hipErrorInvalidValue;
     const size_t lds = sizeof(float) * (128 * 64 + 16 * 128 + 128);
-    hipLaunchKernelGGL((dense_lds_kernel<true, 64>), dim3((J + 63) / 64), dim3(256), lds, s, w, WT, b, styles, n, K, J, 0, avg, psi, col_layer);
+    hipLaunchKernelGGL((dense_lds_kernel<true, 64, 128>), dim3((J + 63) / 64), dim3(256), lds, s, w, WT, b, styles, n, K, J, 0, avg, psi, col_layer);
     return hipGetLastError();
 }
 
 hipError_t launch_torgb(const float* x, const Aff* aff, const float* w, const float* b, float* rgb, uint8_t* img,
-                        int n, int H, int W, int C, int nc, hipStream_t s) {
+                        int n, int H, int W, int C, int nc, int bf16, hipStream_t s) {
     if (nc > 4 || C % 4) return hipErrorInvalidValue;
     const int HW = H * W;
-    if (C == 16) hipLaunchKernelGGL(torgb_direct_kernel<16>, dim3((HW + 255) / 256, n), dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc);
-    else if (C < 16) hipLaunchKernelGGL(torgb_direct_kernel<0>, dim3((HW + 255) / 256, n), dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc);
-    else hipLaunchKernelGGL(torgb_kernel, dim3((HW + 255) / 256, n), dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc);
+    const dim3 grid((HW + 255) / 256, n);
+#define GSA_RGB(BF) \
+    if (C == 16) hipLaunchKernelGGL((torgb_direct_kernel<16, BF>), grid, dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc); \
+    else if (C < 16) hipLaunchKernelGGL((torgb_direct_kernel<0, BF>), grid, dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc); \
+    else hipLaunchKernelGGL(torgb_kernel<BF>, grid, dim3(256), 0, s, x, aff, w, b, rgb, img, HW, C, nc);
+    if (bf16) { GSA_RGB(true) } else { GSA_RGB(false) }
+#undef GSA_RGB
     return hipGetLastError();
 }
 
-hipError_t launch_export_nchw(const float* x, const Aff* aff, float* out, int n, int H, int W, int C, hipStream_t s) {
+hipError_t launch_export_nchw(const float* x, const Aff* aff, float* out, int n, int H, int W, int C, int bf16, hipStream_t s) {
     const int HW = H * W;
-    hipLaunchKernelGGL(export_nchw_kernel, dim3((HW + 63) / 64, C / 16, n), dim3(256), 0, s, x, aff, out, HW, C);
+    if (bf16) hipLaunchKernelGGL(export_nchw_kernel<true>, dim3((HW + 63) / 64, C / 16, n), dim3(256), 0, s, x, aff, out, HW, C);
+    else hipLaunchKernelGGL(export_nchw_kernel<false>, dim3((HW + 63) / 64, C / 16, n), dim3(256), 0, s, x, aff, out, HW, C);
     return hipGetLastError();
 }
 
-hipError_t launch_import_nhwc(const float* in, float* out, int n, int H, int W, int C, hipStream_t s) {
+hipError_t launch_import_nhwc(const float* in, float* out, int n, int H, int W, int C, int bf16, hipStream_t s) {
     const int HW = H * W;
-    hipLaunchKernelGGL(import_nhwc_kernel, dim3((HW + 63) / 64, C / 16, n), dim3(256), 0, s, in, out, HW, C);
+    if (bf16) hipLaunchKernelGGL(import_nhwc_kernel<true>, dim3((HW + 63) / 64, C / 16, n), dim3(256), 0, s, in, out, HW, C);
+    else hipLaunchKernelGGL(import_nhwc_kernel<false>, dim3((HW + 63) / 64, C / 16, n), dim3(256), 0, s, in, out, HW, C);
     return hipGetLastError();
 }
 
 template <int NCLS>
 static hipError_t launch_final_t(const float* src0, int C0, const float* src1, int C1, const float* wpk, const float* bias,
-                                 float* logits, uint8_t* mask, int n, int H, int W, hipStream_t s) {
+                                 float* logits, uint8_t* mask, int n, int H, int W, int bf16, hipStream_t s) {
     const size_t lds = sizeof(float) * 18 * 384;
-    hipLaunchKernelGGL(final_conv_kernel<NCLS>, dim3((H / 16) * (W / 16), n), dim3(256), lds, s, src0, C0, src1, C1, wpk,
-                       bias, logits, mask, H, W, W / 16);
+    if (bf16) hipLaunchKernelGGL((final_conv_kernel<NCLS, true>), dim3((H / 16) * (W / 16), n), dim3(256), lds, s, src0, C0, src1, C1, wpk,
+                                 bias, logits, mask, H, W, W / 16);
+    else hipLaunchKernelGGL((final_conv_kernel<NCLS, false>), dim3((H / 16) * (W / 16), n), dim3(256), lds, s, src0, C0, src1, C1, wpk,
+                            bias, logits, mask, H, W, W / 16);
     return hipGetLastError();
 }
 
 hipError_t launch_final_conv(const float* src0, int C0, const float* src1, int C1, const float* wpk, const float* bias,
-                             float* logits, uint8_t* mask, int n, int H, int W, int ncls, hipStream_t s) {
+                             float* logits, uint8_t* mask, int n, int H, int W, int ncls, int bf16, hipStream_t s) {
     if (H % 16 || W % 16 || C0 % 16 || C1 % 16) return hipErrorInvalidValue;
     switch (ncls) {
-        case 1: return launch_final_t<1>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
-        case 2: return launch_final_t<2>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
-        case 3: return launch_final_t<3>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
-        case 4: return launch_final_t<4>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
-        case 5: return launch_final_t<5>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
-        case 6: return launch_final_t<6>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
-        case 7: return launch_final_t<7>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
-        case 8: return launch_final_t<8>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, s);
+        case 1: return launch_final_t<1>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, bf16, s);
+        case 2: return launch_final_t<2>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, bf16, s);
+        case 3: return launch_final_t<3>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, bf16, s);
+        case 4: return launch_final_t<4>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, bf16, s);
+        case 5: return launch_final_t<5>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, bf16, s);
+        case 6: return launch_final_t<6>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, bf16, s);
+        case 7: return launch_final_t<7>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, bf16, s);
+        case 8: return launch_final_t<8>(src0, C0, src1, C1, wpk, bias, logits, mask, n, H, W, bf16, s);
     }
     return hipErrorInvalidValue;
 }

@@ -578,6 +578,14 @@ static inline float bf16r(float f) {
 }
 #define OPND(v) (bf ? bf16r(v) : (v))
 
+/* bf16 mode, round 2: every activation tensor that lives in HBM is bf16 -- the producer rounds what it stores (statistics
+ * are taken from the fp32 values first), consumers widen exactly */
+static void store_bf16(float* x, size_t n, int bf) {
+    if (!bf) return;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) x[i] = bf16r(x[i]);
+}
+
 /* 3x3 conv, pad 1, NHWC.  in: [Hs][Ws][Cin] (already affine-applied); when up!=0 the
  * logical input is the nearest-x2 upsample of `in` (UpSampling, reference :308-315).
  * out: raw accumulators [H][W][Cout], H = Hs<<up. */
@@ -828,6 +836,7 @@ GSAO_API int gsao_generator_forward(gsao_ctx* c, void* stream, int32_t n, const 
                         if (B->is_deconv) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc, c->bf16);
                         else if (R >= 16) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc, c->bf16);   /* sub-pixel up+conv */
                         else conv3x3(xb, R / 2, R / 2, Cin, 1, B->w1, C, xc, c->bf16, 1);
+                        store_bf16(xc, npix * C, c->bf16);      /* the raw conv_1 output is a stored tensor */
                         blur3x3(xc, R, R, C, B->blur, xa);
                     }
                 } else {
@@ -836,6 +845,7 @@ GSAO_API int gsao_generator_forward(gsao_ctx* c, void* stream, int32_t n, const 
                 }
                 noise_bias_act(xa, R, R, C, nz, B->nscale[k], B->nbias[k]);
                 plane_stats(xa, R, R, C, I1, I2);
+                store_bf16(xa, npix * C, c->bf16);              /* x1 / x2: stored after the statistics were taken */
                 finalize(I1, I2, R * R, C, style, B->gamma[k], B->beta[k], aff);
                 apply_affine(xa, npix, C, aff, xb);
             }
@@ -1001,6 +1011,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
             if (use_wino(R, R, d->F, 0, c->bf16)) conv3x3_wino(fin, R, R, d->I, d->cvt_u, d->F, ya);
             else conv3x3(fin, R, R, d->I, 0, d->cvt_w, d->F, ya, c->bf16, 1);
             bias_bn_act(ya, npix, d->F, d->cvt_b, d->cvt_s, d->cvt_rm, d->cvt_beta);
+            store_bf16(ya, npix * d->F, c->bf16);
             /* concat(prev, cvt) on channels, reference :108-109 */
             if (i > c->d_s0) {
                 for (size_t p = 0; p < npix; ++p) {
@@ -1017,6 +1028,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                 if (R2 >= 16) deconv4x4s2(cat, R, R, d->in_c, d->a_w, d->cs, ya, c->bf16);   /* sub-pixel up+conv */
                 else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya, c->bf16, 1);
                 bias_bn_act(ya, np2, d->cs, d->a_b, d->a_s, d->a_rm, d->a_beta);
+                store_bf16(ya, np2 * d->cs, c->bf16);
                 if (use_wino(R2, R2, d->cs, 0, c->bf16)) conv3x3_wino(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
                 else conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb, c->bf16, 1);
                 bias_bn_act(yb, np2, d->cs, d->b_b, d->b_s, d->b_rm, d->b_beta);
@@ -1036,10 +1048,12 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                                     acc = fmaf(OPND(src[ch]), OPND(d->sc_w[(size_t)ch * d->cs + o]), acc);
                                 }
                                 sc = acc + d->sc_b[o];
+                                if (c->bf16) sc = bf16r(sc);       /* the shortcut is a stored tensor of its own */
                             } else {
                                 sc = src[o];
                             }
                             dst[o] = sc + yv[o];
+                            if (c->bf16) dst[o] = bf16r(dst[o]);
                         }
                     }
             } else {
