@@ -490,3 +490,19 @@ def test_in_process_device_list(torch_cuda, oracle_lib, tmp_path):
     ib, mb = gen2.generate_indexed(40, 5, seed=3)
     assert_same(ia.cpu().numpy(), ib.cpu().numpy(), "indexed image")
     assert_same(ma.cpu().numpy(), mb.cpu().numpy(), "indexed mask")
+
+
+def test_large_activations_stay_bit_exact(torch_cuda, oracle_lib):
+    """The instance-norm statistics are 64-bit fixed-point sums (include/gsa.h states the range: |x| < 2.3e4 per value,
+    rms < 2.9e3 over a 1024^2 plane).  Activations three orders of magnitude above the synthetic weights' O(1) -- one level's
+    conv weights scaled so that its pre-normalisation tensor has rms ~ 1e3 -- are still inside it: same bits as the oracle."""
+    gcfg, gp, dcfg, dp, z, noise = reduced_setup(7, batch=2, trivial_norm=False)
+    gp = dict(gp)
+    for name in ("64_conv_2_weight", "128_deconv_1_weight", "16_conv_1_weight"):
+        gp[name] = (np.asarray(gp[name], np.float32) * np.float32(800.0)).astype(np.float32)
+    gen = _build(gcfg, gp, dcfg, dp, 2)
+    img, mask = gen.generate_batch(z, noise)
+    o = oracle_lib.Oracle(gcfg, gp, dcfg, dp)
+    img_o, mask_o = o.generate(z, noise)
+    assert_same(img.cpu().numpy(), img_o, "image")
+    assert_same(mask.cpu().numpy(), mask_o, "mask")
