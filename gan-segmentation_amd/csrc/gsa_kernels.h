@@ -43,6 +43,7 @@ struct ConvParams {
     int stats_direct;                            // filled by the launcher: EPI_SYNTH sums go to acc with atomics (no partial rows)
     int* stat_rows_host;                         // host pointer or null: the launcher reports the partial rows it used (0 = direct)
     int w_resident;                              // filled by the launcher: whole weight panel LDS-resident (conv3x3 DB form)
+    int group_minor;                             // filled by the launcher (conv3x3_wino): 1-D grid, the channel groups of a tile consecutive on one XCD
     unsigned long long* stamps;   // diagnostic build (-DGSA_STAMP) only: per-phase cycle sums
     int dbg;                      // diagnostic build only: bit0 = stage pixel 0 everywhere (timing of a cache-resident input)
     int prio;                     // experiment (GSA_PRIO): 1 = the wave OUTSIDE its MFMA phase gets the higher issue priority

@@ -1074,12 +1074,23 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
-    const int g = blockIdx.y;
-
-    // contiguous range of the group's tiles, order (n, ty, tx)
-    const int chunk = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int w_begin = xcd_block(blockIdx.x, gridDim.x) * chunk;
-    const int w_end = min(p.total_tiles, w_begin + chunk);
+    // group_minor (launcher: one tile per workgroup, several channel groups, all weight panels together small enough for an
+    // XCD's L2): a 1-D grid in which the G groups of ONE tile are consecutive workgroups of ONE XCD (workgroup b runs on XCD
+    // b % 8), so the tile's input is fetched from HBM once and the other G-1 groups find it in that L2 -- in group-major order
+    // every group re-read the whole input from HBM / MALL (rocprofv3: 1.58x the algorithmic bytes).
+    int g, w_begin, w_end;
+    if (p.group_minor) {
+        const int b = blockIdx.x, j = b >> 3;
+        g = j % p.groups;
+        w_begin = (j / p.groups) * 8 + (b & 7);
+        w_end = w_begin + 1;
+    } else {
+        // contiguous range of the group's tiles, order (n, ty, tx)
+        g = blockIdx.y;
+        const int chunk = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+        w_begin = xcd_block(blockIdx.x, gridDim.x) * chunk;
+        w_end = min(p.total_tiles, w_begin + chunk);
+    }
     if (w_begin >= w_end) return;
     struct Tile { int n, y0, x0, row; };
     auto advance = [&](const Tile& t) {
@@ -2836,7 +2847,12 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
         if (e != hipSuccess) return e;
     }
     if (p.stat_rows_host) *p.stat_rows_host = q.prow;
-    hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256), lds, s, q);
+    // groups of a tile side by side on one XCD when the layer's whole U (16 * Cin * Cout floats) fits comfortably in a 4 MB L2
+    static const bool gm_enabled = !(getenv("GSA_WINO_GM") && atoi(getenv("GSA_WINO_GM")) == 0);
+    q.group_minor = (gm_enabled && !persistent && q.groups > 1 && q.total_tiles % 8 == 0 &&
+                     (size_t)16 * p.C0 * p.Cout * sizeof(float) <= (size_t)2 << 20) ? 1 : 0;
+    if (q.group_minor) hipLaunchKernelGGL(kern, dim3(q.total_tiles * q.groups), dim3(256), lds, s, q);
+    else hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256), lds, s, q);
     return hipGetLastError();
 }
 
