@@ -975,13 +975,22 @@ __global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
     load_item(min(1, nq - 1));
     write_aff(1);
     __syncthreads();
+    unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, sw = 0, sl = 0, sm = 0, sb = 0;
+    (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)sw; (void)sl; (void)sm; (void)sb;
     for (int it = 0; it < nq; ++it) {
+        TICK(k0);
         if (it + 1 < nq) write_item((it + 1) & 1);
+        TICK(k1);
         load_item(min(it + 2, nq - 1));
+        TICK(k2);
         mfma_item(it & 1);
+        TICK(k3);
         write_aff(it & 1);            // entries of item it+2 -> the slot item it used (its reader ran in iteration it-1); read after the barrier
         __syncthreads();              // readers of buffer it&1 done; buffer (it+1)&1 complete
+        TICK(k4);
+        TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(sb, k3, k4);
     }
+    TFLUSH(6, sw); TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(10, sb); TFLUSH(12, (unsigned long long)nq); TFLUSH(15, 1ull);
     // ---- combine the four quarters in the fixed order (s0 + s1) + (s2 + s3); wave w finishes patch w
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) sP[(wave * MT + mt) * 64 + lane] = acc[mt];
