@@ -506,3 +506,33 @@ def test_large_activations_stay_bit_exact(torch_cuda, oracle_lib):
     img_o, mask_o = o.generate(z, noise)
     assert_same(img.cpu().numpy(), img_o, "image")
     assert_same(mask.cpu().numpy(), mask_o, "mask")
+
+
+_SWITCH_WORKER = r'''
+import sys
+sys.path.insert(0, ROOT_DIR)
+from tests.common import bench_setup, golden_bench_outputs, pair_digest
+from gan_segmentation_amd.image_generator import ImageGenerator
+gcfg, gp, dcfg, dp, z, noise = bench_setup("ffhq", 4)
+gen = ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[0], batch_size=4)
+img, mask = gen.generate_batch(z, noise)
+img, mask = img.cpu().numpy(), mask.cpu().numpy()
+assert pair_digest(img[0], mask[0]) == golden_bench_outputs()["ffhq_b4"]["samples"][0]
+print("SWITCH_OK")
+'''
+
+
+@pytest.mark.parametrize("env", [{"GSA_WINO_NT": "2"}, {"GSA_WINO_GM": "0"}, {"GSA_POST_RPT": "1"}, {"GSA_POST_RPT": "8"},
+                                 {"GSA_SIDE_LEVELS": "0"}, {"GSA_WRES": "0", "GSA_SUBRES": "0", "GSA_STATS_DIRECT": "0"}])
+def test_speed_switches_do_not_change_the_bits(torch_cuda, tmp_path, env):
+    """The A/B switches of DESIGN.md section 4 that are NOT part of the canonical arithmetic (channel tile of the Winograd
+    kernel, group order, rows per thread of the post kernel, stream overlap, resident weights / persistent forms / direct
+    statistics) select other kernels or launch shapes, never other results: ffhq 1024^2 batch 4 equals the oracle's digest
+    under each of them.  (Child processes: the switches are read once per process.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "switch_worker.py"
+    script.write_text(_SWITCH_WORKER.replace("ROOT_DIR", repr(root)))
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "SWITCH_OK" in out.stdout, "%r: %s" % (env, out.stdout[-800:] + out.stderr[-2500:])
