@@ -107,12 +107,14 @@ class DatasetWriter:
         self._dispatcher = threading.Thread(target=self._dispatch, daemon=True)
         self._dispatcher.start()
         self.written = 0
+        self.submitted = 0
 
     # -- producer side ----------------------------------------------------------------------
     def submit(self, img, mask, first_index):
         """img (N,R,R,3) u8, mask (N,R,R) u8: torch CUDA tensors (copied asynchronously) or numpy."""
         if self._errors:
             raise self._errors[0]
+        self.submitted += int(img.shape[0])
         if isinstance(img, np.ndarray):
             self._pending.put((None, None, np.ascontiguousarray(img), np.ascontiguousarray(mask), first_index))
             return
@@ -269,6 +271,22 @@ class DatasetWriter:
 
         for f in futs:
             f.add_done_callback(done)
+
+    def drain(self, timeout=600.0):
+        """Block until every pair submitted so far is on disk (the writer stays open)."""
+        import time
+        t0 = time.perf_counter()
+        while True:
+            with self._lock:
+                done = self.written + len(self._errors) >= self.submitted
+            if done:
+                break
+            if time.perf_counter() - t0 > timeout:
+                raise TimeoutError("DatasetWriter.drain: %d of %d pairs written" % (self.written, self.submitted))
+            time.sleep(0.0005)
+        if self._errors:
+            raise self._errors[0]
+        return self.written
 
     def close(self):
         self._pending.put(None)
