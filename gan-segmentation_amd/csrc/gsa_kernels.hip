@@ -1068,17 +1068,22 @@ __global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
 // Staging (AdaIN on read, zero padding, double-buffered LDS image, prefetch two items ahead, resident or streamed
 // weight panel, direct statistics, XCD-aware tile walk) is the structure of conv3x3_mfma's double-buffered form.
 // blockIdx.y = output-channel group, so a resident panel never changes under a persistent workgroup.
-template <int EPI, int NT>
+// CHUNK = staging by 16-byte chunks with the AdaIN coefficients in registers (see "staging by 16-byte chunks" above): measured
+// faster for the layers with >= 64 input channels (g.64 / g.128 / g.256.conv_2 -4..-9 %), slower for the resident-weight layers
+// with <= 32 (d.main_6.b +11 %, d.cvt_8 +5 %), which therefore keep whole-pixel staging with a two-slot LDS coefficient table.
+template <int EPI, int NT, bool CHUNK>
 __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams p) {
     constexpr int NTHR = 256, LH = 18, LW = 18, RS = LW * 16 + 4;
     constexpr int SEG = 16 * 256;                // U floats per (16 couts, 16-channel block): 16 frequencies x [ci][16][cg]
     constexpr int NB4 = SEG / 4, BIT = NT * NB4 / NTHR;      // 16-byte pieces of one (16 couts, block) segment; pieces per thread of a block
-    constexpr int NCH = (LH * LW * 4 + NTHR - 1) / NTHR;     // 16-byte chunk rounds per item
+    constexpr int NCH = CHUNK ? (LH * LW * 4 + NTHR - 1) / NTHR : (LH * LW + NTHR - 1) / NTHR;     // staging rounds per item (chunks or pixels)
+    constexpr int RW = CHUNK ? 1 : 4;                        // 16-byte registers per staged unit
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nblk = p.C0 >> 4;
     const bool wres = p.w_resident != 0;
     float* sA = smem;                            // [2][LH*RS]
     float* sB = sA + 2 * LH * RS;                // resident: [nblk][NT][SEG]; streamed: [2][NT][SEG]
+    f32x4* sAff = reinterpret_cast<f32x4*>(sB + (wres ? nblk : 2) * NT * SEG);   // !CHUNK: [2][16] (mean, A, B, -)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1109,13 +1114,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         return u;
     };
     auto is_edge = [&](const Tile& t) { return t.y0 == 0 || t.x0 == 0 || t.y0 + 16 == p.H || t.x0 + 16 == p.W; };
-    const int part = tid & 3;                    // this thread's four channels of every 16-channel block
-    int t_ly[NCH], t_lx[NCH], t_lds[NCH];        // tile-local coordinates / LDS offset of the chunks this thread stages
+    const int part = tid & 3;                    // CHUNK: this thread's four channels of every 16-channel block
+    int t_ly[NCH], t_lx[NCH], t_lds[NCH];        // tile-local coordinates / LDS offset of the units this thread stages
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-        const int idx = (tid + k * NTHR) >> 2;   // pixel of the halo tile
+        const int idx = CHUNK ? (tid + k * NTHR) >> 2 : tid + k * NTHR;   // pixel of the halo tile
         t_ly[k] = idx / LW - 1; t_lx[k] = idx % LW - 1;
-        t_lds[k] = idx < LH * LW ? (idx / LW) * RS + (idx % LW) * 16 + part * 4 : -1;
+        t_lds[k] = idx < LH * LW ? (idx / LW) * RS + (idx % LW) * 16 + (CHUNK ? part * 4 : 0) : -1;
     }
     int t_rel[NCH];                              // pixel offset from the tile origin (0 for an idle chunk: any valid pixel)
 #pragma unroll
@@ -1147,7 +1152,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         for (int nt = 0; nt < NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const bool has_aff = p.aff0 != nullptr;
-    f32x4 ra[NCH], rb[BIT], raff[4];
+    f32x4 ra[NCH][RW], rb[BIT], raff[4];      // raff: CHUNK: this thread's 4 AdaIN entries; else raff[0] = one entry of the item's 16 (lanes 0-15)
 #pragma unroll
     for (int c = 0; c < 4; ++c) raff[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* wgrp = p.wpk + (size_t)g * NT * nblk * SEG;      // U panels of this output-channel group: [q][cb][SEG]
@@ -1159,29 +1164,46 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
     }
     auto load_item = [&](const Tile& t, int cb, const Chunk (&tp)[NCH]) {
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) ra[k] = load_chunk(p.src0, p.C0, cb * 16 + part * 4, tp[k]);
+        for (int k = 0; k < NCH; ++k) {
+            if constexpr (CHUNK) ra[k][0] = load_chunk(p.src0, p.C0, cb * 16 + part * 4, tp[k]);
+            else load_pixel(ra[k], p.src0, p.C0, cb * 16, TilePixel{tp[k].pix, tp[k].lds});
+        }
         if (!wres) {
 #pragma unroll
             for (int j = 0; j < BIT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wgrp + (size_t)cb * SEG + wsrc[j]);
         }
-        if (has_aff) load_aff4(raff, p.aff0, (size_t)t.n * p.C0 + cb * 16 + part * 4);     // travels with the item
+        if (has_aff) {      // travels with the item
+            if constexpr (CHUNK) load_aff4(raff, p.aff0, (size_t)t.n * p.C0 + cb * 16 + part * 4);
+            else raff[0] = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * p.C0 + cb * 16)[tid & 15];
+        }
+    };
+    auto write_aff_item = [&](int slot) {        // !CHUNK: the item's 16 entries -> LDS slot (read after the next barrier)
+        if constexpr (!CHUNK) {
+            if (has_aff && tid < 16) sAff[slot * 16 + tid] = raff[0];
+        }
+    };
+    auto stage_unit = [&](auto aff_tag, auto mask_tag, float* a_img, const float4* tab, int k, const Chunk& u) {
+        constexpr bool A = decltype(aff_tag)::value, M = decltype(mask_tag)::value;
+        if constexpr (CHUNK) store_chunk<A, false, M>(a_img, ra[k][0], raff, u);
+        else store_pixel<A, false, M>(a_img, ra[k], tab, TilePixel{u.pix, u.lds});
     };
     auto write_item = [&](const Chunk (&tp)[NCH], bool edge, int buf) {
         float* a_img = sA + buf * (LH * RS);
+        const float4* tab = reinterpret_cast<const float4*>(sAff) + buf * 16;
         if (has_aff) {
             if (edge) {
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) store_chunk<true, false, true>(a_img, ra[k], raff, tp[k]);
+                for (int k = 0; k < NCH; ++k) stage_unit(std::true_type{}, std::true_type{}, a_img, tab, k, tp[k]);
             } else {
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) store_chunk<true, false, false>(a_img, ra[k], raff, tp[k]);
+                for (int k = 0; k < NCH; ++k) stage_unit(std::true_type{}, std::false_type{}, a_img, tab, k, tp[k]);
             }
         } else if (edge) {
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) store_chunk<false, false, true>(a_img, ra[k], raff, tp[k]);
+            for (int k = 0; k < NCH; ++k) stage_unit(std::false_type{}, std::true_type{}, a_img, tab, k, tp[k]);
         } else {
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) store_chunk<false, false, false>(a_img, ra[k], raff, tp[k]);
+            for (int k = 0; k < NCH; ++k) stage_unit(std::false_type{}, std::false_type{}, a_img, tab, k, tp[k]);
         }
         if (!wres) {
 #pragma unroll
@@ -1381,10 +1403,15 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         }
     }
     load_item(tc, cb, tpr);
+    if (!CHUNK && has_aff) {
+        write_aff_item(0);
+        __syncthreads();
+    }
     write_item(tpr, is_edge(tc), 0);
     tr = tc; cbr = cb;
     next_item(0, tr, cbr, tpr);
     load_item(tr, cbr, tpr);
+    write_aff_item(1);                 // entries of item 1 -> slot 1 (read after the barrier below)
     __syncthreads();
     unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, sw = 0, sl = 0, sm = 0, se = 0, sb = 0;
     (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)k5; (void)sw; (void)sl; (void)sm; (void)se; (void)sb;
@@ -1405,6 +1432,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
             if (stats_direct && (!has_next || tr.n != tc.n)) flush_stats(tc);
         }
         TICK(k4);
+        write_aff_item(it & 1);        // entries of item it+2 (loaded above) -> the slot item it used; read after the barrier
         __syncthreads();
         TICK(k5);
         TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4); TSUM(sb, k4, k5);
@@ -2809,13 +2837,13 @@ static int wino_nt(const ConvParams& p) {
     return (forced >= 2 && p.Cout % 32 == 0) ? 2 : 1;
 }
 
-template <int EPI, int NT>
+template <int EPI, int NT, bool CHUNK>
 static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int RS = 18 * 16 + 4, SEG = 16 * 256;
     const int nblk = p.C0 / 16;
     const bool wres = (size_t)nblk * NT * SEG * sizeof(float) <= (NT == 1 ? 36 : 72) * 1024;      // whole panel of the group resident (<= 32 input channels)
-    const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * NT * SEG);
-    auto kern = conv3x3_wino<EPI, NT>;
+    const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * NT * SEG) + (CHUNK ? 0 : 32 * sizeof(float4));
+    auto kern = conv3x3_wino<EPI, NT, CHUNK>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
     int num_cus = 0, wgs_per_cu = 0;
@@ -2833,7 +2861,7 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
             if (e != hipSuccess) return e;
             wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
             if (st.occ_n < 8) { st.occ_lds[st.occ_n] = lds; st.occ_k[st.occ_n] = wgs_per_cu; ++st.occ_n; }
-            if (getenv("GSA_VERBOSE")) fprintf(stderr, "gsa: conv3x3_wino<%d,%d> lds %zu B%s -> %d workgroups/CU\n", EPI, NT, lds, wres ? " (resident weights)" : "", k);
+            if (getenv("GSA_VERBOSE")) fprintf(stderr, "gsa: conv3x3_wino<%d,%d,%d> lds %zu B%s -> %d workgroups/CU\n", EPI, NT, (int)CHUNK, lds, wres ? " (resident weights)" : "", k);
         }
     }
     ConvParams q = p;
@@ -2865,17 +2893,28 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// staging form of the Winograd kernel: 16-byte chunks from 64 input channels on, whole pixels below (measured; speed only)
+static bool wino_chunk(const ConvParams& p) {
+    static const int forced = getenv("GSA_WINO_CHUNK") ? atoi(getenv("GSA_WINO_CHUNK")) : -1;
+    return forced >= 0 ? forced != 0 : p.C0 >= 64;
+}
+
 static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s) {
     const int nt = wino_nt(p);
-    if (epi == EPI_SYNTH) return nt == 2 ? launch_wino_t<EPI_SYNTH, 2>(p, n, s) : launch_wino_t<EPI_SYNTH, 1>(p, n, s);
-    return nt == 2 ? launch_wino_t<EPI_DEC, 2>(p, n, s) : launch_wino_t<EPI_DEC, 1>(p, n, s);
+    const bool ch = wino_chunk(p);
+#define GSA_W(EPI) \
+    if (nt == 2) return ch ? launch_wino_t<EPI, 2, true>(p, n, s) : launch_wino_t<EPI, 2, false>(p, n, s); \
+    return ch ? launch_wino_t<EPI, 1, true>(p, n, s) : launch_wino_t<EPI, 1, false>(p, n, s);
+    if (epi == EPI_SYNTH) { GSA_W(EPI_SYNTH) }
+    GSA_W(EPI_DEC)
+#undef GSA_W
 }
 
 // exact C++ name of the instantiation launch_conv3x3 picks (profile labels spell kernels as rocprofv3 prints them)
 const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     static thread_local char buf[128];
     if (conv_uses_wino(p, epi, sc)) {
-        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d, %d>(gsa::ConvParams)", epi, wino_nt(p));
+        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d, %d, %s>(gsa::ConvParams)", epi, wino_nt(p), wino_chunk(p) ? "true" : "false");
         return buf;
     }
     if (conv_uses_ksplit(p, sc)) {
