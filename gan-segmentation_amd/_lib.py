@@ -2,9 +2,8 @@
 
 ``load_library()`` opens the HIP library built in-tree by ``__graft_entry__.build()``
 (csrc/libgsa_hip.so).  There is no CPU fallback: if the library is missing or a call
-fails, a ``GsaError`` is raised.  The same thin table, instantiated with the ``gsao_``
-prefix, drives the CPU oracle from the tests (oracle/binding.py); this module itself never
-opens the oracle.
+fails, a ``GsaError`` is raised.  (The CPU oracle has a ctypes table of its own in
+oracle/binding.py; this module never opens it.)
 """
 import ctypes
 import os
