@@ -616,6 +616,61 @@ int gsa_train_bn_lrelu_bwd(void* stream, int32_t n, int32_t C, int32_t HW, const
     return GSA_OK_;
 }
 
+// ---- SyncBatchNorm: the same kernels with the per-channel sums handed to the host between the two halves (include/gsa_train.h)
+static int bn_launch_reduce(hipStream_t s, int mode, int32_t n, int32_t C, int32_t HW, const float* v, const float* g, const float* gamma,
+                            const float* beta, float eps, const float* mean, const float* var, const uint8_t* mask, float drop_scale,
+                            double* sums) {
+    TRY_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s));
+    const long total = (long)n * HW;
+    const int chunks = (int)((total + 256 * 64 - 1) / (256 * 64));
+    const dim3 grid(C, chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks));
+    if (mode == 0) hipLaunchKernelGGL(bn_reduce_kernel<0>, grid, dim3(256), 0, s, n, C, HW, v, g, gamma, beta, eps, mean, var, mask, drop_scale, sums);
+    else hipLaunchKernelGGL(bn_reduce_kernel<1>, grid, dim3(256), 0, s, n, C, HW, v, g, gamma, beta, eps, mean, var, mask, drop_scale, sums);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+int gsa_train_bn_sums(void* stream, int32_t n, int32_t C, int32_t HW, const float* v, double* sums) {
+    if (n <= 0 || C <= 0 || C > 8192 || HW <= 0 || !v || !sums) return GSA_ERR_INVALID_;
+    return bn_launch_reduce((hipStream_t)stream, 0, n, C, HW, v, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, 1.0f, sums);
+}
+
+int gsa_train_bn_lrelu_fwd_sums(void* stream, int32_t n, int32_t C, int32_t HW, double count, const float* v, const float* gamma,
+                                const float* beta, float eps, float momentum, const double* sums, float* mean, float* var,
+                                float* running_mean, float* running_var, const uint8_t* mask, float drop_scale, float* y) {
+    if (n <= 0 || C <= 0 || C > 8192 || HW <= 0 || !(count >= (double)n * HW) || !v || !gamma || !beta || !sums || !mean || !var || !y)
+        return GSA_ERR_INVALID_;
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)n * HW;
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, C, count, sums, momentum, mean, var, running_mean,
+                       running_var);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total * C)), dim3(256), 0, s, total * C, C, HW, v, gamma, beta, eps, mean, var, mask,
+                       drop_scale, y);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
+int gsa_train_bn_bwd_sums(void* stream, int32_t n, int32_t C, int32_t HW, const float* v, const float* gamma, const float* beta, float eps,
+                          const float* mean, const float* var, const uint8_t* mask, float drop_scale, const float* g, double* sums) {
+    if (n <= 0 || C <= 0 || C > 8192 || HW <= 0 || !v || !gamma || !beta || !mean || !var || !g || !sums) return GSA_ERR_INVALID_;
+    return bn_launch_reduce((hipStream_t)stream, 1, n, C, HW, v, g, gamma, beta, eps, mean, var, mask, drop_scale, sums);
+}
+
+int gsa_train_bn_lrelu_bwd_sums(void* stream, int32_t n, int32_t C, int32_t HW, double count, const float* v, const float* gamma,
+                                const float* beta, float eps, const float* mean, const float* var, const uint8_t* mask, float drop_scale,
+                                const double* sums_all, const double* sums_own, float* g, float* dgamma, float* dbeta) {
+    if (n <= 0 || C <= 0 || C > 8192 || HW <= 0 || !(count >= (double)n * HW) || !v || !gamma || !beta || !mean || !var || !sums_all ||
+        !sums_own || !g || !dgamma || !dbeta)
+        return GSA_ERR_INVALID_;
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)n * HW;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total * C)), dim3(256), 0, s, total * C, C, HW, count, v, gamma, beta, eps, mean, var,
+                       mask, drop_scale, sums_all, g);
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, s, C, sums_own, dgamma, dbeta);
+    TRY_HIP(hipGetLastError());
+    return GSA_OK_;
+}
+
 int gsa_train_softmax_ce(void* stream, int32_t n, int32_t classes, int32_t HW, const float* logits, const int8_t* labels, float* loss,
                          float* dlogits, float grad_scale) {
     if (n <= 0 || classes < 2 || classes > 64 || HW <= 0 || !logits || !labels || !loss || !dlogits) return GSA_ERR_INVALID_;

@@ -23,6 +23,10 @@ def _api():
             "gsa_train_conv_wgrad": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp],
             "gsa_train_bn_lrelu_fwd": [vp, i32, i32, i32, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, f32, vp],
             "gsa_train_bn_lrelu_bwd": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, f32, vp, vp, vp],
+            "gsa_train_bn_sums": [vp, i32, i32, i32, vp, vp],
+            "gsa_train_bn_lrelu_fwd_sums": [vp, i32, i32, i32, c.c_double, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, f32, vp],
+            "gsa_train_bn_bwd_sums": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, f32, vp, vp],
+            "gsa_train_bn_lrelu_bwd_sums": [vp, i32, i32, i32, c.c_double, vp, vp, vp, f32, vp, vp, vp, f32, vp, vp, vp, vp, vp],
             "gsa_train_softmax_ce": [vp, i32, i32, i32, vp, vp, vp, vp, f32],
             "gsa_train_upsample2_bwd": [vp, i32, i32, i32, i32, vp, vp, i32],
             "gsa_train_add": [vp, i64, vp, vp, vp],
@@ -99,6 +103,40 @@ def bn_lrelu_bwd(v, gamma, beta, mean, var, g, dgamma, dbeta, mask=None, drop_sc
     n, C, H, W = v.shape
     _call("gsa_train_bn_lrelu_bwd", current_stream_ptr(v.device), n, C, H * W, _p(v), _p(gamma), _p(beta), eps, _p(mean), _p(var), _p(mask),
           drop_scale, _p(g), _p(dgamma), _p(dbeta))
+    return g
+
+
+def sync_bn_lrelu_fwd(v, gamma, beta, running_mean, running_var, all_reduce, mask=None, drop_scale=1.0, eps=1e-5, momentum=0.9):
+    """SyncBatchNorm form of ``bn_lrelu_fwd`` (reference networks_seg.py:20-21: ``gluon.contrib.nn.SyncBatchNorm``): the
+    per-channel sums and the pixel count go through ``all_reduce(tensor)`` (in place, sum over the ranks) before the
+    statistics are formed.  -> (y, mean, var) with the statistics of the whole (all-rank) batch."""
+    _chk(v, gamma, beta, running_mean, running_var, mask)
+    n, C, H, W = v.shape
+    sums = torch.empty(2 * C + 1, device=v.device, dtype=torch.float64)
+    _call("gsa_train_bn_sums", current_stream_ptr(v.device), n, C, H * W, _p(v), _p(sums))
+    sums[2 * C] = float(n * H * W)
+    all_reduce(sums)
+    count = float(sums[2 * C].item())
+    mean = torch.empty(C, device=v.device, dtype=torch.float32)
+    var = torch.empty(C, device=v.device, dtype=torch.float32)
+    y = torch.empty_like(v)
+    _call("gsa_train_bn_lrelu_fwd_sums", current_stream_ptr(v.device), n, C, H * W, count, _p(v), _p(gamma), _p(beta), eps, momentum,
+          _p(sums), _p(mean), _p(var), _p(running_mean), _p(running_var), _p(mask), drop_scale, _p(y))
+    return y, mean, var, count
+
+
+def sync_bn_lrelu_bwd(v, gamma, beta, mean, var, count, g, dgamma, dbeta, all_reduce, mask=None, drop_scale=1.0, eps=1e-5):
+    """Backward of ``sync_bn_lrelu_fwd``: the two batch means of the gradient are taken over all ranks; dgamma / dbeta
+    receive this rank's share (the gradient all-reduce adds the ranks)."""
+    _chk(v, gamma, beta, mean, var, g, dgamma, dbeta, mask)
+    n, C, H, W = v.shape
+    own = torch.empty(2 * C, device=v.device, dtype=torch.float64)
+    _call("gsa_train_bn_bwd_sums", current_stream_ptr(v.device), n, C, H * W, _p(v), _p(gamma), _p(beta), eps, _p(mean), _p(var), _p(mask),
+          drop_scale, _p(g), _p(own))
+    both = own.clone()
+    all_reduce(both)
+    _call("gsa_train_bn_lrelu_bwd_sums", current_stream_ptr(v.device), n, C, H * W, float(count), _p(v), _p(gamma), _p(beta), eps, _p(mean),
+          _p(var), _p(mask), drop_scale, _p(both), _p(own), _p(g), _p(dgamma), _p(dbeta))
     return g
 
 

@@ -23,7 +23,7 @@ from ._runtime import require_gpu
 
 class DecoderTrainer:
     def __init__(self, cfg, params, device=0, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, seed=1,
-                 dropout_keep=0.5):
+                 dropout_keep=0.5, sync_bn=None, all_reduce=None, world=None):
         require_gpu()
         if not cfg["use_bn"]:
             raise NotImplementedError("training supports the reference's configuration: use_bn=True")
@@ -37,6 +37,11 @@ class DecoderTrainer:
         self.keep = dropout_keep if cfg.get("use_dropout", True) else 1.0
         self.t = 0
         self._eyes = {}
+        # SyncBatchNorm (reference networks_seg.py:20-21,30-31,73-74 under cfg['use_sync_bn']; off in seg_solver.py:120):
+        # batch statistics and their gradient means over the batches of ALL ranks, exchanged as per-channel sums
+        self.sync_bn = bool(cfg.get("use_sync_bn", False)) if sync_bn is None else bool(sync_bn)
+        self._all_reduce = all_reduce if all_reduce is not None else self._dist_all_reduce
+        self._world_override = world    # with a caller-supplied all_reduce: the number of ranks it sums over
         shapes = _weights.decoder_param_shapes(cfg)
         self.p, self.g, self.m, self.v = {}, {}, {}, {}
         for name, shape in shapes.items():
@@ -48,14 +53,28 @@ class DecoderTrainer:
                 self.v[name] = torch.zeros(shape, device=self.dev)
 
     # -- helpers ----------------------------------------------------------------------------------
+    @staticmethod
+    def _dist_all_reduce(t):
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(t)
+
     def _bn_fwd(self, prefix, v, mask=None):
         p = self.p
+        if self.sync_bn:
+            y, mean, var, count = ops.sync_bn_lrelu_fwd(v, p[prefix + ".gamma"], p[prefix + ".beta"], p[prefix + ".running_mean"],
+                                                        p[prefix + ".running_var"], self._all_reduce, mask=mask,
+                                                        drop_scale=1.0 / self.keep)
+            return y, (mean, var, count)
         y, mean, var = ops.bn_lrelu_fwd(v, p[prefix + ".gamma"], p[prefix + ".beta"], p[prefix + ".running_mean"],
                                         p[prefix + ".running_var"], mask=mask, drop_scale=1.0 / self.keep)
         return y, (mean, var)
 
     def _bn_bwd(self, prefix, v, stats, g, mask=None):
         p = self.p
+        if self.sync_bn:
+            return ops.sync_bn_lrelu_bwd(v, p[prefix + ".gamma"], p[prefix + ".beta"], stats[0], stats[1], stats[2], g,
+                                         self.g[prefix + ".gamma"], self.g[prefix + ".beta"], self._all_reduce, mask=mask,
+                                         drop_scale=1.0 / self.keep)
         return ops.bn_lrelu_bwd(v, p[prefix + ".gamma"], p[prefix + ".beta"], stats[0], stats[1], g, self.g[prefix + ".gamma"],
                                 self.g[prefix + ".beta"], mask=mask, drop_scale=1.0 / self.keep)
 
@@ -150,13 +169,13 @@ class DecoderTrainer:
             ops.conv_wgrad(feats[i], None, gv, 3, g[cv + ".0.weight"], g[cv + ".0.bias"])
 
         # ---- data parallel (one process per GPU): sum the gradients over the ranks with RCCL -- the reference's
-        # kvstore 'nccl' (seg_solver.py:55); BatchNorm statistics stay per rank (use_sync_bn=False, :122)
-        world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size()
-            if world > 1:
-                for name in g:
-                    torch.distributed.all_reduce(g[name])
+        # kvstore 'nccl' (seg_solver.py:55); BatchNorm statistics stay per rank unless cfg['use_sync_bn'] (off in the reference, :120)
+        world = self._world_override
+        if world is None:
+            world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        if world > 1:
+            for name in g:
+                self._all_reduce(g[name])
         # ---- Adam (mx.optimizer.Adam; trainer.step(batch_size) -> rescale_grad = 1/batch)
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         for name in g:

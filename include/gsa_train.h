@@ -57,6 +57,27 @@ int gsa_train_bn_lrelu_bwd(void* stream, int32_t n, int32_t C, int32_t HW, const
                            const float* beta, float eps, const float* mean, const float* var, const uint8_t* mask,
                            float drop_scale, float* g, float* dgamma, float* dbeta);
 
+/* SyncBatchNorm (gluon.contrib.nn.SyncBatchNorm when cfg['use_sync_bn'], networks_seg.py:20-21,30-31,73-74): the two calls
+ * above cut at the per-channel sums, so that the host can all-reduce them over the ranks (RCCL, 2*C doubles) in between.
+ *   gsa_train_bn_sums:            sums[c] = sum v, sums[C+c] = sum v*v over this rank's (n, HW)
+ *   gsa_train_bn_lrelu_fwd_sums:  mean/var/running/y as gsa_train_bn_lrelu_fwd, from `sums` over `count` values per channel
+ *                                 (count = the pixels of ALL ranks, >= n*HW)
+ *   gsa_train_bn_bwd_sums:        sums[c] = sum dz, sums[C+c] = sum dz*xhat of this rank (dz = dL/dy through dropout and LeakyReLU)
+ *   gsa_train_bn_lrelu_bwd_sums:  g <- dL/dv with the batch means taken from sums_all / count; dgamma/dbeta += sums_own (this
+ *                                 rank's share: the gradient all-reduce adds the ranks up)
+ * With one rank (sums_all = sums_own, count = n*HW) the results equal the fused calls bit for bit. */
+int gsa_train_bn_sums(void* stream, int32_t n, int32_t C, int32_t HW, const float* v, double* sums);
+int gsa_train_bn_lrelu_fwd_sums(void* stream, int32_t n, int32_t C, int32_t HW, double count, const float* v, const float* gamma,
+                                const float* beta, float eps, float momentum, const double* sums, float* mean, float* var,
+                                float* running_mean, float* running_var, const uint8_t* mask, float drop_scale, float* y);
+int gsa_train_bn_bwd_sums(void* stream, int32_t n, int32_t C, int32_t HW, const float* v, const float* gamma, const float* beta,
+                          float eps, const float* mean, const float* var, const uint8_t* mask, float drop_scale, const float* g,
+                          double* sums);
+int gsa_train_bn_lrelu_bwd_sums(void* stream, int32_t n, int32_t C, int32_t HW, double count, const float* v, const float* gamma,
+                                const float* beta, float eps, const float* mean, const float* var, const uint8_t* mask,
+                                float drop_scale, const double* sums_all, const double* sums_own, float* g, float* dgamma,
+                                float* dbeta);
+
 /* SoftmaxCELoss(axis=1) with sample weight 1 on labelled pixels and 0 on ignored ones (label -1), per-sample mean
  * over H*W (seg_solver.py:243-250, 395-407): loss[n] and dlogits = grad_scale * d(sum_n loss[n])/dlogits. */
 int gsa_train_softmax_ce(void* stream, int32_t n, int32_t classes, int32_t HW, const float* logits,

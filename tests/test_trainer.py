@@ -85,6 +85,82 @@ def test_gradients_match_autograd_directly(features, start_res):
         assert np.abs(got - gref).max() <= 2e-3 * scale + 1e-6, "%s: %.3e of %.3e" % (k, np.abs(got - gref).max(), scale)
 
 
+def test_sync_batchnorm_two_ranks_equal_the_joint_batch():
+    """cfg['use_sync_bn'] (reference networks_seg.py:20-21,30-31,73-74): two ranks with one sample each, exchanging the
+    BatchNorm sums and the gradients, must compute what ONE trainer computes on the two-sample batch.  The ranks are two
+    threads of this process on the one GPU of the box; their all-reduce is a rendezvous that adds the two tensors."""
+    import threading
+    import torch
+    from gan_segmentation_amd import weights as W
+    from gan_segmentation_amd.trainer import DecoderTrainer
+    mr = 5
+    gcfg = W.reduced_generator_config(mr)
+    chans = W.generator_channels(gcfg)
+    dcfg = W.decoder_config(mr, in_channels=chans)
+    dp = W.synthetic_decoder_params(dcfg, seed=8)
+    rng = np.random.default_rng(4)
+    feats = [rng.standard_normal((2, c, 4 << i, 4 << i)).astype(np.float32) for i, c in enumerate(chans)]
+    R = 4 << (len(chans) - 1)
+    labels = rng.integers(-1, 2, (2, R, R)).astype(np.int64)
+    joint = DecoderTrainer(dcfg, dp, lr=0.0, seed=2)
+    masks = joint.dropout_masks([(2, dcfg["features"][i], 4 << i, 4 << i) for i in range(len(chans))])
+    loss_joint = joint.step(feats, labels, masks=masks)
+
+    # world 1 with the switch on: the split calls must reproduce the fused ones
+    alone = DecoderTrainer(dict(dcfg, use_sync_bn=True), dp, lr=0.0, seed=2)
+    assert alone.sync_bn
+    loss_alone = alone.step(feats, labels, masks=masks)
+    assert abs(loss_alone - loss_joint) <= 1e-6 * max(1.0, abs(loss_joint))
+    for k in joint.g:
+        a, b = alone.g[k].cpu().numpy(), joint.g[k].cpu().numpy()
+        assert np.abs(a - b).max() <= 1e-5 * max(1e-6, np.abs(b).max()), k
+
+    slots, barrier = [None, None], threading.Barrier(2)
+
+    def make_all_reduce(rank):
+        def all_reduce(t):
+            slots[rank] = t
+            barrier.wait()
+            total = slots[0] + slots[1]
+            torch.cuda.synchronize()
+            barrier.wait()
+            t.copy_(total)
+        return all_reduce
+
+    ranks = [DecoderTrainer(dcfg, dp, lr=0.0, seed=2, sync_bn=True, all_reduce=make_all_reduce(r), world=2) for r in range(2)]
+    losses, errors = [None, None], []
+
+    def run(r):
+        try:
+            losses[r] = ranks[r].step([f[r:r + 1] for f in feats], labels[r:r + 1], masks=[mk[r:r + 1].contiguous() for mk in masks])
+        except Exception as e:      # a failing rank must not leave the other one at the barrier
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    assert abs(0.5 * (losses[0] + losses[1]) - loss_joint) <= 1e-5 * max(1.0, abs(loss_joint))
+    for k in joint.g:
+        ref = joint.g[k].cpu().numpy()
+        scale = max(1e-6, np.abs(ref).max())
+        for r in range(2):
+            got = ranks[r].g[k].cpu().numpy()
+            assert np.abs(got - ref).max() <= 2e-4 * scale + 1e-7, "%s rank %d: %.3e of %.3e" % (k, r, np.abs(got - ref).max(), scale)
+    for k in ("cvt_block_1.1.running_mean", "main_block_2.1.base_layers.4.running_var"):
+        if k in joint.p:
+            for r in range(2):
+                assert np.allclose(ranks[r].p[k].cpu().numpy(), joint.p[k].cpu().numpy(), rtol=1e-5, atol=1e-6), k
+    # per-rank statistics (the reference's default) are NOT the joint batch's: the switch matters
+    plain = DecoderTrainer(dcfg, dp, lr=0.0, seed=2)
+    plain.step([f[0:1] for f in feats], labels[0:1], masks=[mk[0:1].contiguous() for mk in masks])
+    k = "cvt_block_1.1.running_mean"
+    assert not np.allclose(plain.p[k].cpu().numpy(), joint.p[k].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_solver_fit_learns_and_saves(tmp_path):
     """SegSolver.fit over annotator sample files: the loss falls, the checkpoint reloads, evaluate improves."""
     from PIL import Image
