@@ -109,6 +109,7 @@ struct gsa_ctx {
     StatPart* partials = nullptr;
     StatPart* stat_acc = nullptr;
     unsigned* stat_tickets = nullptr;
+    unsigned* map_bar = nullptr;            // grid barrier of the fused mapping network: arrivals, generation, error word
     unsigned long long* stamps = nullptr;   // diagnostic build only
     float* din[kMaxLevels] = {nullptr};
     float* cvt[kMaxLevels] = {nullptr};
@@ -831,6 +832,8 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
         for (int i = 0; i < 2; ++i)
             if (int rc = dev_alloc(c, N * L, &c->lat[i], T)) return rc;
         if (int rc = dev_alloc(c, N * c->style_cols, &c->styles, T)) return rc;
+        if (int rc = dev_alloc(c, 4, &c->map_bar, T)) return rc;
+        HIP_TRY(hipMemset(c->map_bar, 0, 4 * sizeof(unsigned)));
         size_t maxact = 0;
         int maxC = 0;
         for (int l = 0; l < c->nlev; ++l) {
@@ -881,13 +884,18 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
     const int L = c->gc.latent_size, nlev = c->nlev;
     const double N = n;
     // mapping network: PixelNorm, 8 x (dense + LeakyReLU)
-    { Launch lp(c, s, "pixelnorm_kernel", "g.mapping.pixelnorm", 3.0 * N * L, 8.0 * N * L);
-      HIP_TRY(launch_pixelnorm(z, c->lat[0], n, L, s)); }
     int cur = 0;
-    for (int i = 0; i < 8; ++i) {
-        Launch lp(c, s, "dense_kernel", "g.mapping.dense", 2.0 * N * L * L, 4.0 * (L * (double)L + 2 * N * L));
-        HIP_TRY(launch_dense(c->lat[cur], c->map_wt[i], c->map_b[i], c->lat[cur ^ 1], n, L, L, 1, s));
-        cur ^= 1;
+    if (mapping_fused(L, c->device)) {
+        Launch lp(c, s, "mapping_kernel", "g.mapping", 3.0 * N * L + 16.0 * N * L * L, 4.0 * (8.0 * L * (double)L + 18 * N * L));
+        HIP_TRY(launch_mapping(z, c->map_wt, c->map_b, c->lat, c->map_bar, n, L, c->device, s));
+    } else {
+        { Launch lp(c, s, "pixelnorm_kernel", "g.mapping.pixelnorm", 3.0 * N * L, 8.0 * N * L);
+          HIP_TRY(launch_pixelnorm(z, c->lat[0], n, L, s)); }
+        for (int i = 0; i < 8; ++i) {
+            Launch lp(c, s, "dense_kernel", "g.mapping.dense", 2.0 * N * L * L, 4.0 * (L * (double)L + 2 * N * L));
+            HIP_TRY(launch_dense(c->lat[cur], c->map_wt[i], c->map_b[i], c->lat[cur ^ 1], n, L, L, 1, s));
+            cur ^= 1;
+        }
     }
     const float* w = c->lat[cur];
     { Launch lp(c, s, "styles_kernel", "g.styles", 2.0 * N * L * c->style_cols, 4.0 * ((double)L * c->style_cols + N * c->style_cols));

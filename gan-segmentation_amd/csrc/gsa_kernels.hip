@@ -2313,6 +2313,103 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const fl
 }
 
 // ------------------------------------------------------------------------------------------
+// The whole mapping network in ONE launch: PixelNorm + 8 x (dense 512->512 + LeakyReLU) were ten dependent launches of
+// ~10 us each at the head of every step (a quarter of a batch-1 step's latency chain).  Here L/16 workgroups each own 16
+// output columns of every layer; the layers are separated by a self-resetting grid barrier (an arrival count and a
+// generation word in global memory: the last arriver clears the count and bumps the generation), the weight slice of the
+// next layer is fetched into registers BEFORE the barrier wait, and the activations cross the barrier through a
+// ping-pong buffer in global memory (release fence before arriving, acquire fence after leaving).
+// Arithmetic per output is unchanged: the canonical k-ordered fmaf chains of pixelnorm_kernel / dense_lds_kernel.
+// All L/16 workgroups must be resident together (the launcher keeps the grid within the CU count); a wait gives up after
+// ~0.2 s instead of spinning forever if that is ever violated (the error word is then set and the results are garbage).
+struct MappingParams {
+    const float* z;            // [n][L]
+    const float* wt[8];        // [K = L][J = L]
+    const float* b[8];
+    float* lat[2];             // ping-pong activations [n][L]; layer i reads lat[i & 1] ... the result is in lat[0]
+    unsigned* bar;             // [0] arrivals, [1] generation, [2] error word
+    int n, L;
+};
+
+__device__ __forceinline__ void mapping_grid_barrier(unsigned* bar, unsigned groups) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();                                   // release: this workgroup's stores before its arrival
+        if (atomicAdd(bar, 1u) == groups - 1) {
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            atomicAdd(bar + 1, 1u);
+        } else {
+            int spins = 0;
+            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 20)) { atomicExch(bar + 2, 1u); break; }     // never expected: see the header
+            }
+        }
+        __threadfence();                                   // acquire: the other workgroups' stores
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void mapping_kernel(MappingParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = p.L, tid = threadIdx.x, jl = tid & 15, ng = tid >> 4;
+    float* sW = smem;                  // [L][16]
+    float* sX = sW + L * 16;           // [16][L]
+    __shared__ float rn[16];
+    const int j0 = blockIdx.x * 16;
+    const int nw4 = L * 4 / 256;       // float4s of the weight slice per thread (L a multiple of 64)
+    f32x4 rw[8];                       // L <= 512
+    auto load_w = [&](int layer) {
+        for (int i = 0; i < nw4; ++i) {
+            const int idx = tid + i * 256, kr = idx >> 2, c4 = (idx & 3) * 4;
+            rw[i] = *reinterpret_cast<const f32x4*>(p.wt[layer] + (size_t)kr * L + j0 + c4);
+        }
+    };
+    auto store_w = [&]() {
+        for (int i = 0; i < nw4; ++i) reinterpret_cast<f32x4*>(sW)[tid + i * 256] = rw[i];
+    };
+    load_w(0);
+    // PixelNorm: every workgroup normalises all samples itself (n chains of L steps, one lane each) and writes ITS 16
+    // columns of the result -- no barrier needed before layer 0 reads them ... but layer 0 needs ALL columns, so the
+    // normalised rows live in LDS (sX) per 16-sample chunk and are recomputed per chunk below.
+    for (int layer = 0; layer < 8; ++layer) {
+        if (layer) mapping_grid_barrier(p.bar, gridDim.x);
+        __syncthreads();
+        store_w();
+        if (layer + 1 < 8) load_w(layer + 1);
+        const float* x = layer ? p.lat[layer & 1] : p.z;
+        float* y = p.lat[(layer + 1) & 1];
+        const float bj = p.b[layer][j0 + jl];
+        for (int n0 = 0; n0 < p.n; n0 += 16) {
+            const int nn = min(16, p.n - n0);
+            if (n0) __syncthreads();
+            for (int idx = tid; idx < nn * L; idx += 256) sX[idx] = x[(size_t)n0 * L + idx];
+            __syncthreads();
+            if (layer == 0) {                               // PixelNorm of this chunk (pixelnorm_kernel's chain)
+                if (tid < nn) {
+                    float ss = 0.0f;
+                    const float* r = sX + tid * L;
+                    for (int k = 0; k < L; ++k) ss = fmaf(r[k], r[k], ss);
+                    rn[tid] = 1.0f / sqrtf(ss / (float)L + 1e-8f);
+                }
+                __syncthreads();
+                for (int idx = tid; idx < nn * L; idx += 256) sX[idx] = sX[idx] * rn[idx / L];
+                __syncthreads();
+            }
+            if (ng < nn) {
+                float a = 0.f;
+                const float* xs = sX + ng * L;
+#pragma unroll 8
+                for (int k = 0; k < L; ++k) a = fmaf(xs[k], sW[k * 16 + jl], a);
+                y[(size_t)(n0 + ng) * L + j0 + jl] = lrelu(a + bj);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // toRGB (1x1 conv + bias) and the uint8 image of _transform_gan_back.
 // One thread per pixel reading its own channels: right for C <= 16 (one 64-byte line per pixel).
 template <int CT, bool BF>      // CT = 16: the channel count is known, all four 16-byte loads of a pixel are issued up front
@@ -3187,6 +3284,39 @@ hipError_t launch_dense(const float* x, const float* WT, const float* b, float* 
     const size_t lds = sizeof(float) * (256 * 16 + 16 * 256 + 256);
     hipLaunchKernelGGL((dense_lds_kernel<false, 16, 256>), dim3((J + 15) / 16), dim3(256), lds, s, x, WT, b, y, n, K, J, act,
                        (const float*)nullptr, (const float*)nullptr, (const int*)nullptr);
+    return hipGetLastError();
+}
+
+// the fused mapping network applies when its L/16 workgroups are certainly co-resident (see mapping_kernel)
+bool mapping_fused(int L, int device) {
+    static const bool enabled = !(getenv("GSA_MAPFUSE") && atoi(getenv("GSA_MAPFUSE")) == 0);
+    if (!enabled || L % 64 || L > 512 || L < 64) return false;
+    int num_cus;
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        num_cus = device_cus(device);
+    }
+    return L / 16 <= num_cus / 2;
+}
+
+hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, float* const* lat, unsigned* bar, int n, int L,
+                          int device, hipStream_t s) {
+    if (!mapping_fused(L, device)) return hipErrorInvalidValue;
+    MappingParams p;
+    p.z = z;
+    for (int i = 0; i < 8; ++i) { p.wt[i] = wt[i]; p.b[i] = b[i]; }
+    p.lat[0] = lat[0]; p.lat[1] = lat[1];
+    p.bar = bar; p.n = n; p.L = L;
+    auto kern = mapping_kernel;
+    static LaunchState states[kMaxDevices];
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        hipError_t e = prepare_kernel(kern, states[device]);
+        if (e != hipSuccess) return e;
+    }
+    const size_t lds = sizeof(float) * (size_t)(L * 16 + 16 * L);
+    hipLaunchKernelGGL(kern, dim3(L / 16), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
