@@ -109,7 +109,8 @@ struct gsa_ctx {
     StatPart* partials = nullptr;
     StatPart* stat_acc = nullptr;
     unsigned* stat_tickets = nullptr;
-    unsigned* map_bar = nullptr;            // grid barrier of the fused mapping network: arrivals, generation, error word
+    unsigned* map_ctl = nullptr;            // fused mapping network: launch number, error word
+    unsigned long long* map_ll[2] = {nullptr, nullptr};   // its {value, tag} exchange buffers
     unsigned long long* stamps = nullptr;   // diagnostic build only
     float* din[kMaxLevels] = {nullptr};
     float* cvt[kMaxLevels] = {nullptr};
@@ -832,8 +833,12 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
         for (int i = 0; i < 2; ++i)
             if (int rc = dev_alloc(c, N * L, &c->lat[i], T)) return rc;
         if (int rc = dev_alloc(c, N * c->style_cols, &c->styles, T)) return rc;
-        if (int rc = dev_alloc(c, 4, &c->map_bar, T)) return rc;
-        HIP_TRY(hipMemset(c->map_bar, 0, 4 * sizeof(unsigned)));
+        if (int rc = dev_alloc(c, 4, &c->map_ctl, T)) return rc;
+        HIP_TRY(hipMemset(c->map_ctl, 0, 4 * sizeof(unsigned)));
+        for (int i = 0; i < 2; ++i) {
+            if (int rc = dev_alloc(c, N * L, &c->map_ll[i], T)) return rc;
+            HIP_TRY(hipMemset(c->map_ll[i], 0, N * L * sizeof(unsigned long long)));     // tag 0 never matches a launch
+        }
         size_t maxact = 0;
         int maxC = 0;
         for (int l = 0; l < c->nlev; ++l) {
@@ -887,7 +892,7 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
     int cur = 0;
     if (mapping_fused(L, c->device)) {
         Launch lp(c, s, "mapping_kernel", "g.mapping", 3.0 * N * L + 16.0 * N * L * L, 4.0 * (8.0 * L * (double)L + 18 * N * L));
-        HIP_TRY(launch_mapping(z, c->map_wt, c->map_b, c->lat, c->map_bar, n, L, c->device, s));
+        HIP_TRY(launch_mapping(z, c->map_wt, c->map_b, c->map_ll, c->lat[0], c->map_ctl, n, L, c->device, s));
     } else {
         { Launch lp(c, s, "pixelnorm_kernel", "g.mapping.pixelnorm", 3.0 * N * L, 8.0 * N * L);
           HIP_TRY(launch_pixelnorm(z, c->lat[0], n, L, s)); }

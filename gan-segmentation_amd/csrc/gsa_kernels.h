@@ -80,8 +80,8 @@ hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);
 hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_t s);
 // PixelNorm + the eight mapping layers in one launch (result in lat[0]); mapping_fused: whether it applies to this latent size
 bool mapping_fused(int L, int device);
-hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, float* const* lat, unsigned* bar, int n, int L,
-                          int device, hipStream_t s);
+hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, unsigned long long* const* ll, float* out, unsigned* ctl,
+                          int n, int L, int device, hipStream_t s);
 hipError_t launch_dense(const float* x, const float* WT, const float* b, float* y, int n, int K, int J,
                         int lrelu, hipStream_t s);
 hipError_t launch_styles(const float* w, const float* avg, const float* psi, const float* WT, const float* b,

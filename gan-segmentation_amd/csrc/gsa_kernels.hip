@@ -2315,83 +2315,107 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const fl
 // ------------------------------------------------------------------------------------------
 // The whole mapping network in ONE launch: PixelNorm + 8 x (dense 512->512 + LeakyReLU) were ten dependent launches of
 // ~10 us each at the head of every step (a quarter of a batch-1 step's latency chain).  Here L/16 workgroups each own 16
-// output columns of every layer; the layers are separated by a self-resetting grid barrier (an arrival count and a
-// generation word in global memory: the last arriver clears the count and bumps the generation), the weight slice of the
-// next layer is fetched into registers BEFORE the barrier wait, and the activations cross the barrier through a
-// ping-pong buffer in global memory (release fence before arriving, acquire fence after leaving).
+// output columns of every layer and hand their activations to the others through global memory WITHOUT a barrier: every
+// value travels as one naturally aligned 64-bit word {fp32 bits, tag}, written and read with relaxed device-scope atomics,
+// where tag = 8 * launch number + layer + 1.  A consumer simply re-reads a word until it carries the tag it expects --
+// value and flag arrive together, so no fence, no arrival counter and no cache maintenance is involved (a grid barrier
+// was built first: its five dependent device-scope round trips per layer across the eight L2s made the fused kernel no
+// faster than the ten launches).  The launch number lives in device memory and is bumped by workgroup 0 when it has
+// finished (every other workgroup has read it by then: workgroup 0 cannot finish a layer without their outputs), so the
+// kernel is replayable from a captured graph; stale words of earlier launches never match.  Two ping-pong buffers
+// suffice: a workgroup can only be two layers ahead of another one after that one has consumed the older buffer.
 // Arithmetic per output is unchanged: the canonical k-ordered fmaf chains of pixelnorm_kernel / dense_lds_kernel.
-// All L/16 workgroups must be resident together (the launcher keeps the grid within the CU count); a wait gives up after
-// ~0.2 s instead of spinning forever if that is ever violated (the error word is then set and the results are garbage).
+// All L/16 workgroups must be resident together (the launcher keeps the grid within half the CU count); a wait gives up
+// after ~0.2 s instead of spinning forever if that is ever violated (the error word is set, the results are garbage).
 struct MappingParams {
-    const float* z;            // [n][L]
-    const float* wt[8];        // [K = L][J = L]
+    const float* z;                  // [n][L]
+    const float* wt[8];              // [K = L][J = L]
     const float* b[8];
-    float* lat[2];             // ping-pong activations [n][L]; layer i reads lat[i & 1] ... the result is in lat[0]
-    unsigned* bar;             // [0] arrivals, [1] generation, [2] error word
+    unsigned long long* ll[2];       // ping-pong {value, tag} words [n][L]; layer i writes ll[(i + 1) & 1]
+    float* out;                      // [n][L] the dlatents (plain fp32)
+    unsigned* ctl;                   // [0] launch number, [1] error word
     int n, L;
 };
-
-__device__ __forceinline__ void mapping_grid_barrier(unsigned* bar, unsigned groups) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();                                   // release: this workgroup's stores before its arrival
-        if (atomicAdd(bar, 1u) == groups - 1) {
-            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
-            atomicAdd(bar + 1, 1u);
-        } else {
-            int spins = 0;
-            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 20)) { atomicExch(bar + 2, 1u); break; }     // never expected: see the header
-            }
-        }
-        __threadfence();                                   // acquire: the other workgroups' stores
-    }
-    __syncthreads();
-}
 
 __global__ __launch_bounds__(256) void mapping_kernel(MappingParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = p.L, tid = threadIdx.x, jl = tid & 15, ng = tid >> 4;
-    float* sW = smem;                  // [L][16]
-    float* sX = sW + L * 16;           // [16][L]
-    __shared__ float rn[16];
+    const int WS = L + 4;              // row stride of the transposed weight slice: 16 lanes x 16-byte reads hit 64 distinct banks
+    float* sW = smem;                  // [16 columns][WS]: column-major, so that a thread reads 4 consecutive k of ITS column at once
+    float* sX = sW + 16 * WS;          // [16 samples][L]
+    float* rn = sX + 16 * L;           // [16]
     const int j0 = blockIdx.x * 16;
-    const int nw4 = L * 4 / 256;       // float4s of the weight slice per thread (L a multiple of 64)
-    f32x4 rw[8];                       // L <= 512
+    const int nw4 = L * 4 / 256;       // float4s of the weight slice per thread (L a multiple of 64, <= 512)
+    const unsigned tag0 = __hip_atomic_load(p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u;
+    f32x4 rw[8];
     auto load_w = [&](int layer) {
-        for (int i = 0; i < nw4; ++i) {
-            const int idx = tid + i * 256, kr = idx >> 2, c4 = (idx & 3) * 4;
-            rw[i] = *reinterpret_cast<const f32x4*>(p.wt[layer] + (size_t)kr * L + j0 + c4);
-        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nw4) {
+                const int idx = tid + i * 256, kr = idx >> 2, c4 = (idx & 3) * 4;
+                rw[i] = *reinterpret_cast<const f32x4*>(p.wt[layer] + (size_t)kr * L + j0 + c4);
+            }
     };
     auto store_w = [&]() {
-        for (int i = 0; i < nw4; ++i) reinterpret_cast<f32x4*>(sW)[tid + i * 256] = rw[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nw4) {
+                const int idx = tid + i * 256, kr = idx >> 2, c4 = (idx & 3) * 4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sW[(c4 + c) * WS + kr] = rw[i][c];
+            }
+    };
+    // a 16-sample chunk of the previous layer's output -> sX: all words are requested at once, the ones that do not carry
+    // the expected tag yet are requested again
+    auto fetch_x = [&](const unsigned long long* src, int n0, int nn, unsigned tag) {
+        const int cnt = nn * L;                          // <= 8192 words: 32 per thread
+        unsigned pending = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if (tid + i * 256 < cnt) pending |= 1u << i;
+        int spins = 0;
+        while (pending) {
+            unsigned long long v[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (pending >> i & 1) v[i] = __hip_atomic_load(src + (size_t)n0 * L + tid + i * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if ((pending >> i & 1) && (unsigned)(v[i] >> 32) == tag) {
+                    sX[tid + i * 256] = __uint_as_float((unsigned)v[i]);
+                    pending &= ~(1u << i);
+                }
+            if (pending) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 20)) { atomicExch(p.ctl + 1, 1u); break; }      // never expected: see the header
+            }
+        }
     };
     load_w(0);
-    // PixelNorm: every workgroup normalises all samples itself (n chains of L steps, one lane each) and writes ITS 16
-    // columns of the result -- no barrier needed before layer 0 reads them ... but layer 0 needs ALL columns, so the
-    // normalised rows live in LDS (sX) per 16-sample chunk and are recomputed per chunk below.
     for (int layer = 0; layer < 8; ++layer) {
-        if (layer) mapping_grid_barrier(p.bar, gridDim.x);
-        __syncthreads();
+        if (layer) __syncthreads();                        // every thread is done with sW / sX of the previous layer
         store_w();
         if (layer + 1 < 8) load_w(layer + 1);
-        const float* x = layer ? p.lat[layer & 1] : p.z;
-        float* y = p.lat[(layer + 1) & 1];
         const float bj = p.b[layer][j0 + jl];
         for (int n0 = 0; n0 < p.n; n0 += 16) {
             const int nn = min(16, p.n - n0);
             if (n0) __syncthreads();
-            for (int idx = tid; idx < nn * L; idx += 256) sX[idx] = x[(size_t)n0 * L + idx];
+            if (layer == 0) {
+                for (int idx = tid; idx < nn * L / 4; idx += 256)
+                    reinterpret_cast<f32x4*>(sX)[idx] = *reinterpret_cast<const f32x4*>(p.z + (size_t)n0 * L + idx * 4);
+            } else {
+                fetch_x(p.ll[layer & 1], n0, nn, tag0 + (unsigned)layer);
+            }
             __syncthreads();
             if (layer == 0) {                               // PixelNorm of this chunk (pixelnorm_kernel's chain)
                 if (tid < nn) {
                     float ss = 0.0f;
-                    const float* r = sX + tid * L;
-                    for (int k = 0; k < L; ++k) ss = fmaf(r[k], r[k], ss);
+                    const f32x4* r = reinterpret_cast<const f32x4*>(sX + tid * L);
+#pragma unroll 4
+                    for (int k4 = 0; k4 < L / 4; ++k4) {
+                        const f32x4 v = r[k4];
+                        ss = fmaf(v[0], v[0], ss); ss = fmaf(v[1], v[1], ss); ss = fmaf(v[2], v[2], ss); ss = fmaf(v[3], v[3], ss);
+                    }
                     rn[tid] = 1.0f / sqrtf(ss / (float)L + 1e-8f);
                 }
                 __syncthreads();
@@ -2400,12 +2424,27 @@ __global__ __launch_bounds__(256) void mapping_kernel(MappingParams p) {
             }
             if (ng < nn) {
                 float a = 0.f;
-                const float* xs = sX + ng * L;
-#pragma unroll 8
-                for (int k = 0; k < L; ++k) a = fmaf(xs[k], sW[k * 16 + jl], a);
-                y[(size_t)(n0 + ng) * L + j0 + jl] = lrelu(a + bj);
+                const f32x4* xs = reinterpret_cast<const f32x4*>(sX + ng * L);
+                const f32x4* ws = reinterpret_cast<const f32x4*>(sW + jl * WS);
+#pragma unroll 4
+                for (int k4 = 0; k4 < L / 4; ++k4) {
+                    const f32x4 xv = xs[k4], wv = ws[k4];
+                    a = fmaf(xv[0], wv[0], a);
+                    a = fmaf(xv[1], wv[1], a);
+                    a = fmaf(xv[2], wv[2], a);
+                    a = fmaf(xv[3], wv[3], a);
+                }
+                const float yv = lrelu(a + bj);
+                const size_t o = (size_t)(n0 + ng) * L + j0 + jl;
+                if (layer == 7) p.out[o] = yv;
+                else __hip_atomic_store(p.ll[(layer + 1) & 1] + o, ((unsigned long long)(tag0 + (unsigned)layer + 1u) << 32) | __float_as_uint(yv),
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    }
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        if (tid == 0) atomicAdd(p.ctl, 1u);
     }
 }
 
@@ -3299,14 +3338,14 @@ bool mapping_fused(int L, int device) {
     return L / 16 <= num_cus / 2;
 }
 
-hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, float* const* lat, unsigned* bar, int n, int L,
-                          int device, hipStream_t s) {
+hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, unsigned long long* const* ll, float* out, unsigned* ctl,
+                          int n, int L, int device, hipStream_t s) {
     if (!mapping_fused(L, device)) return hipErrorInvalidValue;
     MappingParams p;
     p.z = z;
     for (int i = 0; i < 8; ++i) { p.wt[i] = wt[i]; p.b[i] = b[i]; }
-    p.lat[0] = lat[0]; p.lat[1] = lat[1];
-    p.bar = bar; p.n = n; p.L = L;
+    p.ll[0] = ll[0]; p.ll[1] = ll[1];
+    p.out = out; p.ctl = ctl; p.n = n; p.L = L;
     auto kern = mapping_kernel;
     static LaunchState states[kMaxDevices];
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
@@ -3315,7 +3354,7 @@ hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, flo
         hipError_t e = prepare_kernel(kern, states[device]);
         if (e != hipSuccess) return e;
     }
-    const size_t lds = sizeof(float) * (size_t)(L * 16 + 16 * L);
+    const size_t lds = sizeof(float) * (size_t)(16 * (L + 4) + 16 * L + 16);
     hipLaunchKernelGGL(kern, dim3(L / 16), dim3(256), lds, s, p);
     return hipGetLastError();
 }
