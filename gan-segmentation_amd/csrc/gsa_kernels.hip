@@ -1047,6 +1047,46 @@ __global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
     act_store4<BF>(p.out, ((size_t)(n * p.H + y) * p.W + xb + xj) * p.Cout + g * 16 + cq4, vt);
 }
 
+// Packed fp32 adds for the Winograd transforms: one v_pk_add_f32 per two additions (neg modifiers for a subtraction; the
+// same IEEE results).  hipcc scalarises a <4 x float> add whose only users are element extracts -- each component feeds its
+// own MFMA -- into four v_add_f32 / v_sub_f32 (and folds every other spelling of the subtraction back into one), so the
+// instruction is written out.  f32 MFMAs and vector-ALU instructions share the SIMD's issue time:
+// every instruction saved is MFMA time gained.
+// Hazards: the compiler's hazard recognizer does not see through inline asm, so the two software-managed ones are handled
+// here.  A vector-ALU result needs 2 wait states before an MFMA reads it as an operand: the transformed patch goes through
+// valu_settle() (s_nop 1 with the four vectors of a frequency row as in/out operands) before the MFMAs of that row.  An MFMA RESULT needs 11 wait
+// states after an 8-pass MFMA before a vector-ALU instruction reads it: the accumulators go through mfma_settle() before the
+// first packed add.  (The waits for the LDS reads feeding an asm are inserted by the compiler from its register operands.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x4 add4(const f32x4& a, const f32x4& b) {
+    const f32x2 lo = pk_add2(a.xy, b.xy), hi = pk_add2(a.zw, b.zw);
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) {
+    const f32x2 lo = pk_sub2(a.xy, b.xy), hi = pk_sub2(a.zw, b.zw);
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ void valu_settle(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));      // not volatile: ordered by its operands only
+}
+// 12 wait states with the sixteen accumulators of one output-channel tile as in/out operands: every later read of them is
+// ordered behind it
+__device__ __forceinline__ void mfma_settle(f32x4 (&a)[16]) {
+    asm("s_nop 7\n\ts_nop 3"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+                   "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
+
 // ------------------------------------------------------------------------------------------
 // conv3x3 (pad 1, stride 1, one source) in WINOGRAD F(2x2, 3x3) form on v_mfma_f32_16x16x4_f32.
 //
@@ -1277,14 +1317,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         for (int nt = 0; nt < NT; ++nt) {
             // output transform Y = A^T M A: rows s0 = (M0+M1)+M2, s1 = (M1-M2)-M3, then the same along the columns;
             // register component = Winograd tile (b1, b0) of the lane's 4x4 patch
-            f32x4 s0[4], s1[4];
+            f32x4 s0[4], s1[4], m[16];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) m[f] = acc[f][nt];
+            mfma_settle(m);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s0[j] = (acc[j][nt] + acc[4 + j][nt]) + acc[8 + j][nt];
-                s1[j] = (acc[4 + j][nt] - acc[8 + j][nt]) - acc[12 + j][nt];
+                s0[j] = add4(add4(m[j], m[4 + j]), m[8 + j]);
+                s1[j] = sub4(sub4(m[4 + j], m[8 + j]), m[12 + j]);
             }
-            const f32x4 y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];     // tile row 0: x = 0, 1
-            const f32x4 y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];     // tile row 1
+            const f32x4 y00 = add4(add4(s0[0], s0[1]), s0[2]), y01 = sub4(sub4(s0[1], s0[2]), s0[3]);     // tile row 0: x = 0, 1
+            const f32x4 y10 = add4(add4(s1[0], s1[1]), s1[2]), y11 = sub4(sub4(s1[1], s1[2]), s1[3]);     // tile row 1
 #pragma unroll
             for (int f = 0; f < 16; ++f) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             unsigned long long I1 = 0, I2 = 0;
@@ -1347,18 +1390,19 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
             const f32x4 d1 = *reinterpret_cast<const f32x4*>(a_img + 1 * RS + c * 16);
             const f32x4 d2 = *reinterpret_cast<const f32x4*>(a_img + 2 * RS + c * 16);
             const f32x4 d3 = *reinterpret_cast<const f32x4*>(a_img + 3 * RS + c * 16);
-            V[0 * 4 + c] = d0 - d2;
-            V[1 * 4 + c] = d1 + d2;
-            V[2 * 4 + c] = d2 - d1;
-            V[3 * 4 + c] = d1 - d3;
+            V[0 * 4 + c] = sub4(d0, d2);
+            V[1 * 4 + c] = add4(d1, d2);
+            V[2 * 4 + c] = sub4(d2, d1);
+            V[3 * 4 + c] = sub4(d1, d3);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x4 t0 = V[i * 4 + 0], t1 = V[i * 4 + 1], t2 = V[i * 4 + 2], t3 = V[i * 4 + 3];
-            V[i * 4 + 0] = t0 - t2;
-            V[i * 4 + 1] = t1 + t2;
-            V[i * 4 + 2] = t2 - t1;
-            V[i * 4 + 3] = t1 - t3;
+            V[i * 4 + 0] = sub4(t0, t2);
+            V[i * 4 + 1] = add4(t1, t2);
+            V[i * 4 + 2] = sub4(t2, t1);
+            V[i * 4 + 3] = sub4(t1, t3);
+            valu_settle(V[i * 4 + 0], V[i * 4 + 1], V[i * 4 + 2], V[i * 4 + 3]);
         }
         // sixteen GEMMs: per frequency one chain over the block's channels (cg ascending), four frequencies interleaved
 #pragma unroll
