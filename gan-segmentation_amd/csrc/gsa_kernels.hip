@@ -873,15 +873,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 // combined through LDS in the fixed order (s0 + s1) + (s2 + s3) -- the canonical arithmetic of these layers (DESIGN.md;
 // oracle conv3x3 use_ksplit), so the result is still bit-exact and batch-independent.
 // Workgroup = one TH x TH tile (TH = 4, 8) x 16 output channels of one sample.
-template <int TH, int EPI, bool BF>
-__global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
-    constexpr int NTHR = 256, MT = (TH / 4) * (TH / 4), PW = TH / 4;
-    constexpr int LH = TH + 2, LW = TH + 2;
+// PS = 2 (8x8 tiles): EIGHT waves -- wave (quarter, half) multiplies its quarter over two of the four patches, and the 400 staged
+// (pixel, block) units of an item are one per thread instead of four: per item a wave issues 72 MFMAs instead of 144 and
+// stages a quarter of what it did, with two waves per SIMD to overlap the phases.  Same chains, same combine: same bits.
+template <int TH, int EPI, bool BF, int PS>
+__global__ __launch_bounds__(256 * PS) void conv3x3_ksplit(ConvParams p) {
+    constexpr int NTHR = 256 * PS, MT = (TH / 4) * (TH / 4), PW = TH / 4;
+    constexpr int MTW = MT / PS;                      // patches per wave
+    constexpr int LH = TH + 2, LW = TH + 2, NPX = LH * LW;
     constexpr int PX = BF ? 8 : 16, TS = BF ? 128 : 256, KQ = BF ? 2 : 4;
     constexpr int RS = LW * PX + (BF ? 4 : 8);
     constexpr int SEG = 9 * TS, IMG = LH * RS;
     constexpr int NB4 = 4 * SEG / 4, BIT = (NB4 + NTHR - 1) / NTHR;         // weights of an item: four blocks
-    static_assert(LH * LW <= NTHR, "one staged pixel per thread and block");
+    constexpr int QPT = PS == 1 ? 4 : 1;              // (pixel, block) units a staging thread handles per item
+    static_assert(PS == 1 || (PS == 2 && MT == 4 && 4 * NPX <= NTHR), "patch split: 8x8 tiles, one staged unit per thread");
+    static_assert(NPX <= NTHR, "one staged pixel per thread and block");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                                 // [2][4][IMG]
     float* sB = sA + 2 * 4 * IMG;                     // [2][4][SEG]
@@ -889,7 +895,8 @@ __global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
     f32x4* sP = sAff + 2 * 4 * 16;                    // [4 quarters][MT][64 lanes] partial accumulators
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = K quarter
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quarter = wave & 3, half = wave >> 2;   // K quarter, patch half (PS == 2)
     const int i16 = lane & 15, kq = lane >> 4;
     const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
     const int g = blockIdx.y, n = blockIdx.z;
@@ -897,30 +904,34 @@ __global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
     const int nblk = p.C0 >> 4, nq = nblk >> 2;       // items per tile = blocks per quarter
     const bool has_aff = p.aff0 != nullptr;
 
+    const int sq0 = PS == 1 ? 0 : tid / NPX;          // first (only) block of the item this thread stages
     TilePixel tp;
     {
-        const int ly = tid / LW, lx = tid % LW;
+        const int st = PS == 1 ? tid : tid % NPX;
+        const int ly = st / LW, lx = st % LW;
         const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-        const bool stage = tid < LH * LW;
+        const bool stage = PS == 1 ? tid < NPX : tid < 4 * NPX;
         const bool inside = stage && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         tp.lds = stage ? ly * RS + lx * PX : -1;
         tp.pix = inside ? (n * p.Hs + (gy >> p.up)) * p.Ws + (gx >> p.up) : -1;
     }
-    int abase[MT];
+    int abase[MTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        abase[mt] = ((mt / PW) * 4 + (i16 >> 2)) * RS + ((mt % PW) * 4 + (i16 & 3)) * PX + kq * KQ;
+    for (int m = 0; m < MTW; ++m) {
+        const int mt = half * MTW + m;
+        abase[m] = ((mt / PW) * 4 + (i16 >> 2)) * RS + ((mt % PW) * 4 + (i16 & 3)) * PX + kq * KQ;
+    }
     const int bbase = (kq * 16 + i16) * KQ;
 
-    f32x4 acc[MT];
+    f32x4 acc[MTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 ra[4][4], rb[BIT], rf;
+    for (int m = 0; m < MTW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[QPT][4], rb[BIT], rf;
     rf = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* wgrp = p.wpk + (size_t)g * nblk * SEG;
     auto load_item = [&](int it) {                    // blocks q*nq + it, q = 0..3
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load_pixel<BF>(ra[q], p.src0, p.C0, (q * nq + it) * 16, tp);
+        for (int u = 0; u < QPT; ++u) load_pixel<BF>(ra[u], p.src0, p.C0, ((min(sq0, 3) + u) * nq + it) * 16, tp);
 #pragma unroll
         for (int j = 0; j < BIT; ++j) {
             const int i = min(tid + j * NTHR, NB4 - 1);
@@ -934,35 +945,36 @@ __global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
     };
     auto write_item = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int u = 0; u < QPT; ++u) {
+            const int q = min(sq0, 3) + u;
             float* a_img = sA + (buf * 4 + q) * IMG;
             const float4* tab = reinterpret_cast<const float4*>(sAff) + (buf * 4 + q) * 16;
-            if (has_aff) store_pixel<true, BF, true>(a_img, ra[q], tab, tp);
-            else store_pixel<false, BF, true>(a_img, ra[q], tab, tp);
+            if (has_aff) store_pixel<true, BF, true>(a_img, ra[u], tab, tp);
+            else store_pixel<false, BF, true>(a_img, ra[u], tab, tp);
         }
 #pragma unroll
         for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * 4 * SEG)[min(tid + j * NTHR, NB4 - 1)] = rb[j];
     };
     auto mfma_item = [&](int buf) {                   // this wave's block of the item
-        const float* a_img = sA + (buf * 4 + wave) * IMG;
-        const float* b_img = sB + (buf * 4 + wave) * SEG + bbase;
+        const float* a_img = sA + (buf * 4 + quarter) * IMG;
+        const float* b_img = sB + (buf * 4 + quarter) * SEG + bbase;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = (tap / 3) * RS + (tap % 3) * PX;
             if constexpr (BF) {
                 const s16x4 b = *reinterpret_cast<const s16x4*>(b_img + tap * TS);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(a_img + abase[mt] + toff), b, acc[mt], 0, 0, 0);
+                for (int m = 0; m < MTW; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(a_img + abase[m] + toff), b, acc[m], 0, 0, 0);
             } else {
-                f32x4 a[MT];
+                f32x4 a[MTW];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_img + abase[mt] + toff);
+                for (int m = 0; m < MTW; ++m) a[m] = *reinterpret_cast<const f32x4*>(a_img + abase[m] + toff);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(b_img + tap * 256);
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[cg], acc[mt], 0, 0, 0);
+                    for (int m = 0; m < MTW; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][cg], b[cg], acc[m], 0, 0, 0);
             }
         }
     };
@@ -993,7 +1005,7 @@ __global__ __launch_bounds__(256) void conv3x3_ksplit(ConvParams p) {
     TFLUSH(6, sw); TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(10, sb); TFLUSH(12, (unsigned long long)nq); TFLUSH(15, 1ull);
     // ---- combine the four quarters in the fixed order (s0 + s1) + (s2 + s3); wave w finishes patch w
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) sP[(wave * MT + mt) * 64 + lane] = acc[mt];
+    for (int m = 0; m < MTW; ++m) sP[(quarter * MT + half * MTW + m) * 64 + lane] = acc[m];
     __syncthreads();
     if (wave >= MT) return;
     const int mt = wave;
@@ -2964,12 +2976,12 @@ bool conv_uses_ksplit(const ConvParams& p, bool sc) {
     return enabled && !sc && p.src1 == nullptr && p.C1 == 0 && p.C0 >= 64 && p.C0 % 64 == 0 && (p.H <= 8 || (p.H <= 32 && p.Cout <= 32)) && p.H == p.W && p.Cout % 16 == 0;
 }
 
-template <int TH, int EPI, bool BF>
+template <int TH, int EPI, bool BF, int PS>
 static hipError_t launch_ksplit_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int MT = (TH / 4) * (TH / 4), PX = BF ? 8 : 16, TS = BF ? 128 : 256;
     constexpr int RS = (TH + 2) * PX + (BF ? 4 : 8), IMG = (TH + 2) * RS, SEG = 9 * TS;
     const size_t lds = sizeof(float) * (2 * 4 * IMG + 2 * 4 * SEG) + sizeof(float4) * (2 * 4 * 16 + 4 * MT * 64);
-    auto kern = conv3x3_ksplit<TH, EPI, BF>;
+    auto kern = conv3x3_ksplit<TH, EPI, BF, PS>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
     {
@@ -2984,18 +2996,24 @@ static hipError_t launch_ksplit_t(const ConvParams& p, int n, hipStream_t s) {
     q.prow = q.tiles_x * q.tiles_y * MT;
     q.stats_direct = 0;
     if (p.stat_rows_host) *p.stat_rows_host = q.prow;
-    hipLaunchKernelGGL(kern, dim3(q.tiles_x * q.tiles_y, q.groups, n), dim3(256), lds, s, q);
+    hipLaunchKernelGGL(kern, dim3(q.tiles_x * q.tiles_y, q.groups, n), dim3(256 * PS), lds, s, q);
     return hipGetLastError();
 }
 
+// waves per workgroup of the 8x8 form: 8 (patch split) unless GSA_KSPLIT_PS=1 (speed only, same bits)
+static int ksplit_ps() {
+    static const int forced = getenv("GSA_KSPLIT_PS") ? atoi(getenv("GSA_KSPLIT_PS")) : 2;
+    return forced == 1 ? 1 : 2;
+}
+
 static hipError_t launch_ksplit(const ConvParams& p, int epi, int n, hipStream_t s) {
-#define GSA_KS(TH, BF) \
-    if ((p.H == 4 ? 4 : 8) == TH && (p.bf16 != 0) == BF) { \
-        if (epi == EPI_RAW) return launch_ksplit_t<TH, EPI_RAW, BF>(p, n, s); \
-        if (epi == EPI_SYNTH) return launch_ksplit_t<TH, EPI_SYNTH, BF>(p, n, s); \
-        return launch_ksplit_t<TH, EPI_DEC, BF>(p, n, s); \
+#define GSA_KS(TH, BF, PS) \
+    if ((p.H == 4 ? 4 : 8) == TH && (p.bf16 != 0) == BF && (TH == 4 ? 1 : ksplit_ps()) == PS) { \
+        if (epi == EPI_RAW) return launch_ksplit_t<TH, EPI_RAW, BF, PS>(p, n, s); \
+        if (epi == EPI_SYNTH) return launch_ksplit_t<TH, EPI_SYNTH, BF, PS>(p, n, s); \
+        return launch_ksplit_t<TH, EPI_DEC, BF, PS>(p, n, s); \
     }
-    GSA_KS(4, false) GSA_KS(8, false) GSA_KS(4, true) GSA_KS(8, true)
+    GSA_KS(4, false, 1) GSA_KS(8, false, 1) GSA_KS(8, false, 2) GSA_KS(4, true, 1) GSA_KS(8, true, 1) GSA_KS(8, true, 2)
 #undef GSA_KS
     return hipErrorInvalidValue;
 }
@@ -3098,7 +3116,7 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
         return buf;
     }
     if (conv_uses_ksplit(p, sc)) {
-        snprintf(buf, sizeof buf, "void gsa::conv3x3_ksplit<%d, %d, %s>(gsa::ConvParams)", p.H == 4 ? 4 : 8, epi, p.bf16 ? "true" : "false");
+        snprintf(buf, sizeof buf, "void gsa::conv3x3_ksplit<%d, %d, %s, %d>(gsa::ConvParams)", p.H == 4 ? 4 : 8, epi, p.bf16 ? "true" : "false", p.H == 4 ? 1 : ksplit_ps());
         return buf;
     }
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
