@@ -854,7 +854,9 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
         if (int rc = dev_alloc(c, N * maxact, &c->t_raw, T)) return rc;
         if (int rc = dev_alloc(c, N * maxact, &c->x1, T)) return rc;
         if (int rc = dev_alloc(c, N * maxC, &c->aff1, T)) return rc;
+        prow_elems = std::max(prow_elems, (size_t)64 * maxC);
         if (int rc = dev_alloc(c, N * prow_elems, &c->partials, T)) return rc;
+        HIP_TRY(hipMemset(c->partials, 0, N * prow_elems * sizeof(StatPart)));     // all zero between layers: finalize_kernel clears what it read
         if (int rc = dev_alloc(c, N * maxC, &c->stat_acc, T)) return rc;
         HIP_TRY(hipMemset(c->stat_acc, 0, N * maxC * sizeof(StatPart)));
         if (int rc = dev_alloc(c, N * ((maxC + 63) / 64), &c->stat_tickets, T)) return rc;

@@ -2099,6 +2099,14 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
         }
     }
     __syncthreads();
+    if ((int)gridDim.x > p.prow) {       // more blocks than rows: the blocks ADD to row (block mod rows) of the all-zero partials
+        for (int i = threadIdx.x; i < p.C; i += 256) {
+            StatPart* a = p.partials + ((size_t)n * p.prow + (blockIdx.x & (kDirectRows - 1))) * p.C + i;
+            atomicAdd(&a->s1, sstat[i]);
+            atomicAdd(&a->s2, sstat[p.C + i]);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < p.C; i += 256) {
         StatPart sp; sp.s1 = sstat[i]; sp.s2 = sstat[p.C + i];
         p.partials[((size_t)n * p.prow + blockIdx.x) * p.C + i] = sp;
@@ -2203,6 +2211,14 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
         }
     }
     __syncthreads();
+    if ((int)gridDim.x > p.prow) {       // more blocks than rows: the blocks ADD to row (block mod rows) of the all-zero partials
+        for (int i = threadIdx.x; i < p.C; i += 256) {
+            StatPart* a = p.partials + ((size_t)n * p.prow + (blockIdx.x & (kDirectRows - 1))) * p.C + i;
+            atomicAdd(&a->s1, sstat[i]);
+            atomicAdd(&a->s2, sstat[p.C + i]);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < p.C; i += 256) {
         StatPart sp; sp.s1 = sstat[i]; sp.s2 = sstat[p.C + i];
         p.partials[((size_t)n * p.prow + blockIdx.x) * p.C + i] = sp;
@@ -2228,20 +2244,28 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p, int row
         const int r0 = blockIdx.z * rows_per_block;
         const int r1 = min(p.prow, r0 + rows_per_block);
         const StatPart* base = p.partials + (size_t)n * p.prow * p.C + c;
-#pragma unroll 4
-        for (int r = r0 + rg; r < r1; r += nrg) {      // independent loads: keep several in flight
+#pragma unroll 16
+        for (int r = r0 + rg; r < r1; r += nrg) {      // independent loads, all in flight together (one memory round trip)
             const StatPart sp = base[(size_t)r * p.C];
             I1 += sp.s1; I2 += sp.s2;
         }
+        // the rows go back to zero: the producers that ADD to their rows (64-bit atomics on at most kDirectRows rows) rely on
+        // `partials` being all zero between layers -- no memset launch per layer
+        StatPart zero; zero.s1 = 0ull; zero.s2 = 0ull;
+        StatPart* wbase = const_cast<StatPart*>(base);
+        for (int r = r0 + rg; r < r1; r += nrg) wbase[(size_t)r * p.C] = zero;
     }
     sh[0][threadIdx.x] = I1; sh[1][threadIdx.x] = I2;
     __syncthreads();
+    const bool single = gridDim.z == 1;      // one block per channel group: no accumulator round trip, no ticket
     if (rg == 0 && c < p.C) {
         for (int k = 1; k < nrg; ++k) { I1 += sh[0][k * cblk + cl]; I2 += sh[1][k * cblk + cl]; }
-        atomicAdd(&p.acc[(size_t)n * p.C + c].s1, I1);
-        atomicAdd(&p.acc[(size_t)n * p.C + c].s2, I2);
+        if (!single) {
+            atomicAdd(&p.acc[(size_t)n * p.C + c].s1, I1);
+            atomicAdd(&p.acc[(size_t)n * p.C + c].s2, I2);
+        }
     }
-    if (gridDim.z > 1) {     // several blocks per channel group: the last arriver finalizes
+    if (!single) {     // several blocks per channel group: the last arriver finalizes
         __threadfence();
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -2255,9 +2279,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p, int row
         __threadfence();
     }
     if (rg == 0 && c < p.C) {
-        StatPart* ap = p.acc + (size_t)n * p.C + c;
-        I1 = atomicExch(&ap->s1, 0ull);      // read the total and clear it for the next layer
-        I2 = atomicExch(&ap->s2, 0ull);
+        if (!single) {
+            StatPart* ap = p.acc + (size_t)n * p.C + c;
+            I1 = atomicExch(&ap->s1, 0ull);      // read the total and clear it for the next layer
+            I2 = atomicExch(&ap->s2, 0ull);
+        }
         const double inv_hw = 1.0 / (double)p.HW;   // HW is a power of two
         const double m = (double)(long long)I1 * (1.0 / kStatScale1) * inv_hw;
         const double e2 = (double)(long long)I2 * (1.0 / kStatScale2) * inv_hw;
@@ -2841,6 +2867,15 @@ static int device_cus(int dev) {     // caller holds g_launch_mu
 }
 
 // first launch of `kern` on device `dev`: allow the full 160 KB of dynamic LDS
+// few statistic rows (GSA_FEWROWS=0: one row per workgroup / wave as in round 1): producers with more workgroups than
+// kDirectRows ADD to row (workgroup mod kDirectRows) of the all-zero `partials` instead of writing a row each, so that
+// finalize_kernel always finds at most kDirectRows rows per sample: one block per channel group, every row load in flight at
+// once, no accumulator round trip and no ticket (it took 9-18 us per launch behind the 1024-row producers, ~3 us now)
+static bool few_rows() {
+    static const bool enabled = !(getenv("GSA_FEWROWS") && atoi(getenv("GSA_FEWROWS")) == 0);
+    return enabled;
+}
+
 template <class K>
 static hipError_t prepare_kernel(K kern, LaunchState& st) {
     if (st.attr_done) return hipSuccess;
@@ -2940,11 +2975,7 @@ static hipError_t launch_conv_t(const ConvParams& p, int n, hipStream_t s) {
     const int grid = persistent ? num_cus * wgs_per_cu : q.total_tiles;
     static const bool direct_enabled = !(getenv("GSA_STATS_DIRECT") && atoi(getenv("GSA_STATS_DIRECT")) == 0);
     q.stats_direct = (direct_enabled && EPI == EPI_SYNTH && NBUF == 2 && persistent && p.partials != nullptr) ? 1 : 0;
-    if (q.stats_direct) {
-        q.prow = kDirectRows;
-        hipError_t e = hipMemsetAsync(p.partials, 0, sizeof(StatPart) * (size_t)n * kDirectRows * p.Cout, s);
-        if (e != hipSuccess) return e;
-    }
+    if (q.stats_direct) q.prow = kDirectRows;      // the rows are all zero between layers (finalize_kernel clears what it read)
     if (p.stat_rows_host) *p.stat_rows_host = q.prow;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, s, q);
     return hipGetLastError();
@@ -3075,12 +3106,10 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     const bool persistent = p.C0 <= 32 && q.total_tiles > slots;
     const int gx = persistent ? slots : q.total_tiles;
     static const bool direct_enabled = !(getenv("GSA_STATS_DIRECT") && atoi(getenv("GSA_STATS_DIRECT")) == 0);
-    q.stats_direct = (direct_enabled && EPI == EPI_SYNTH && persistent && p.partials != nullptr) ? 1 : 0;
-    if (q.stats_direct) {
-        q.prow = kDirectRows;
-        hipError_t e = hipMemsetAsync(p.partials, 0, sizeof(StatPart) * (size_t)n * kDirectRows * p.Cout, s);
-        if (e != hipSuccess) return e;
-    }
+    // direct statistics: always for persistent workgroups; for one-tile workgroups when the layer would otherwise write
+    // more than kDirectRows rows (few_rows).  The rows are all zero between layers (finalize_kernel clears what it read).
+    q.stats_direct = (direct_enabled && EPI == EPI_SYNTH && p.partials != nullptr && (persistent || (few_rows() && q.prow > kDirectRows))) ? 1 : 0;
+    if (q.stats_direct) q.prow = kDirectRows;
     if (p.stat_rows_host) *p.stat_rows_host = q.prow;
     // groups of a tile side by side on one XCD when the layer's whole U (16 * Cin * Cout floats) fits comfortably in a 4 MB L2
     static const bool gm_enabled = !(getenv("GSA_WINO_GM") && atoi(getenv("GSA_WINO_GM")) == 0);
@@ -3341,9 +3370,15 @@ static int post_rpt(const PostParams& p) {
     return p.H >= 64 ? 4 : 1;
 }
 
-int post_rows_used(const PostParams& p) {
+// workgroups per sample of the form launch_post picks
+static int post_blocks(const PostParams& p) {
     const int rpt = post_rpt(p);
     return rpt == 1 ? post_prow(p.H, p.W, p.C) : ((p.H / rpt) * (p.W / 4) * (p.C / 4) + 255) / 256;
+}
+
+int post_rows_used(const PostParams& p) {
+    const int blocks = post_blocks(p);
+    return few_rows() ? std::min(blocks, kDirectRows) : blocks;
 }
 
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
@@ -3351,7 +3386,7 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
     PostParams q = p;
     const int rpt = post_rpt(p);
     q.prow = post_rows_used(p);
-    dim3 grid(q.prow, n);
+    dim3 grid(post_blocks(p), n);
     const size_t lds = sizeof(unsigned long long) * 2 * p.C;
 #define GSA_POST(BF) \
     if (rpt == 8) hipLaunchKernelGGL((post_rows_kernel<8, BF>), grid, dim3(256), lds, s, q); \
