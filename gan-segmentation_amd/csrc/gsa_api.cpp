@@ -833,8 +833,8 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
         for (int i = 0; i < 2; ++i)
             if (int rc = dev_alloc(c, N * L, &c->lat[i], T)) return rc;
         if (int rc = dev_alloc(c, N * c->style_cols, &c->styles, T)) return rc;
-        if (int rc = dev_alloc(c, 4, &c->map_ctl, T)) return rc;
-        HIP_TRY(hipMemset(c->map_ctl, 0, 4 * sizeof(unsigned)));
+        if (int rc = dev_alloc(c, 2 + kMapSlices, &c->map_ctl, T)) return rc;
+        HIP_TRY(hipMemset(c->map_ctl, 0, (2 + kMapSlices) * sizeof(unsigned)));
         for (int i = 0; i < 2; ++i) {
             if (int rc = dev_alloc(c, N * L, &c->map_ll[i], T)) return rc;
             HIP_TRY(hipMemset(c->map_ll[i], 0, N * L * sizeof(unsigned long long)));     // tag 0 never matches a launch

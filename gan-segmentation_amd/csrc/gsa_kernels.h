@@ -79,6 +79,7 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s);
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);
 hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_t s);
 // PixelNorm + the eight mapping layers in one launch (result in lat[0]); mapping_fused: whether it applies to this latent size
+constexpr int kMapSlices = 8;     // most sample slices of the fused mapping network (launch-number words ctl[2 .. 2 + kMapSlices))
 bool mapping_fused(int L, int device);
 hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, unsigned long long* const* ll, float* out, unsigned* ctl,
                           int n, int L, int device, hipStream_t s);

@@ -2343,7 +2343,7 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const fl
     const int jc = j < J ? j : J - 1;
     float ps = 1.0f, om = 0.0f;
     if (STYLE) { ps = psi[col_layer[jc]]; om = 1.0f - ps; }
-    for (int n0 = 0; n0 < n; n0 += 16) {
+    for (int n0 = 16 * (int)blockIdx.y; n0 < n; n0 += 16 * (int)gridDim.y) {      // blockIdx.y: 16-sample chunks side by side
         const int nn = min(16, n - n0);
         float acc[SPT];                             // samples n0 + ng + G*i
 #pragma unroll
@@ -2415,7 +2415,7 @@ struct MappingParams {
     const float* b[8];
     unsigned long long* ll[2];       // ping-pong {value, tag} words [n][L]; layer i writes ll[(i + 1) & 1]
     float* out;                      // [n][L] the dlatents (plain fp32)
-    unsigned* ctl;                   // [0] launch number, [1] error word
+    unsigned* ctl;                   // [1] error word, [2 + slice] launch number of the slice (kMapSlices slices at most)
     int n, L;
 };
 
@@ -2428,7 +2428,10 @@ __global__ __launch_bounds__(256) void mapping_kernel(MappingParams p) {
     float* rn = sX + 16 * L;           // [16]
     const int j0 = blockIdx.x * 16;
     const int nw4 = L * 4 / 256;       // float4s of the weight slice per thread (L a multiple of 64, <= 512)
-    const unsigned tag0 = __hip_atomic_load(p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u;
+    // blockIdx.y = slice: the 16-sample chunks y, y + gridDim.y, ... form an independent copy of the exchange (samples never
+    // mix), with its own launch-number word ctl[2 + y]
+    unsigned* ctl = p.ctl + 2 + blockIdx.y;
+    const unsigned tag0 = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u;
     f32x4 rw[8];
     auto load_w = [&](int layer) {
 #pragma unroll
@@ -2469,7 +2472,7 @@ __global__ __launch_bounds__(256) void mapping_kernel(MappingParams p) {
                 }
             if (pending) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 20)) { atomicExch(p.ctl + 1, 1u); break; }      // never expected: see the header
+                if (++spins > (1 << 20)) { atomicExch(p.ctl + 1, 1u); break; }      // never expected: see the header (ctl[1] = error word)
             }
         }
     };
@@ -2479,9 +2482,10 @@ __global__ __launch_bounds__(256) void mapping_kernel(MappingParams p) {
         store_w();
         if (layer + 1 < 8) load_w(layer + 1);
         const float bj = p.b[layer][j0 + jl];
-        for (int n0 = 0; n0 < p.n; n0 += 16) {
+        const int nfirst = 16 * (int)blockIdx.y, nstep = 16 * (int)gridDim.y;
+        for (int n0 = nfirst; n0 < p.n; n0 += nstep) {
             const int nn = min(16, p.n - n0);
-            if (n0) __syncthreads();
+            if (n0 != nfirst) __syncthreads();
             if (layer == 0) {
                 for (int idx = tid; idx < nn * L / 4; idx += 256)
                     reinterpret_cast<f32x4*>(sX)[idx] = *reinterpret_cast<const f32x4*>(p.z + (size_t)n0 * L + idx * 4);
@@ -2526,7 +2530,7 @@ __global__ __launch_bounds__(256) void mapping_kernel(MappingParams p) {
     }
     if (blockIdx.x == 0) {
         __syncthreads();
-        if (tid == 0) atomicAdd(p.ctl, 1u);
+        if (tid == 0) atomicAdd(ctl, 1u);
     }
 }
 
@@ -3452,7 +3456,14 @@ hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, uns
         if (e != hipSuccess) return e;
     }
     const size_t lds = sizeof(float) * (size_t)(16 * (L + 4) + 16 * L + 16);
-    hipLaunchKernelGGL(kern, dim3(L / 16), dim3(256), lds, s, p);
+    // slices of 16-sample chunks side by side, as many as stay co-resident (the exchange spins)
+    int num_cus;
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        num_cus = device_cus(device);
+    }
+    const int slices = std::max(1, std::min(std::min((n + 15) / 16, kMapSlices), (num_cus / 2) / (L / 16)));
+    hipLaunchKernelGGL(kern, dim3(L / 16, slices), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -3460,7 +3471,7 @@ hipError_t launch_styles(const float* w, const float* avg, const float* psi, con
                          const int* col_layer, float* styles, int n, int K, int J, hipStream_t s) {
     if (K % 128 || J % 4) return hipErrorInvalidValue;
     const size_t lds = sizeof(float) * (128 * 64 + 16 * 128 + 128);
-    hipLaunchKernelGGL((dense_lds_kernel<true, 64, 128>), dim3((J + 63) / 64), dim3(256), lds, s, w, WT, b, styles, n, K, J, 0, avg, psi, col_layer);
+    hipLaunchKernelGGL((dense_lds_kernel<true, 64, 128>), dim3((J + 63) / 64, std::min((n + 15) / 16, 8)), dim3(256), lds, s, w, WT, b, styles, n, K, J, 0, avg, psi, col_layer);
     return hipGetLastError();
 }
 
