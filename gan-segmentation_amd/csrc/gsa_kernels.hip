@@ -2363,6 +2363,19 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const fl
             if (STYLE) for (int idx = tid; idx < KC; idx += 256) sAvg[idx] = avg[k0 + idx];
 #pragma unroll
             for (int i = 0; i < NW4; ++i) reinterpret_cast<f32x4*>(sW)[tid + i * 256] = rw[i];
+            // STYLE: when every column of the workgroup has the same psi (the rule: psi changes at ONE column, a multiple of
+            // 64), the truncated latent x' = avg*(1-psi) + w*psi is formed ONCE per (sample, k) here instead of once per
+            // (sample, k, column) in the chains below -- the same three roundings either way
+            bool pre = false;
+            if (STYLE) {
+                pre = __syncthreads_and(ps == psi[col_layer[min(j0, J - 1)]]) != 0;
+                if (pre) {
+                    for (int idx = tid; idx < nn * KC; idx += 256) {
+                        const float t0 = sAvg[idx % KC] * om, t1 = sX[idx] * ps;
+                        sX[idx] = t0 + t1;
+                    }
+                }
+            }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < SPT; ++i) {
@@ -2370,11 +2383,15 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const fl
                 if (s < nn) {
                     float a = acc[i];
                     const float* xs = sX + s * KC;
+                    if (STYLE && !pre) {
 #pragma unroll 8
-                    for (int k = 0; k < KC; ++k) {
-                        float xv = xs[k];
-                        if (STYLE) { const float t0 = sAvg[k] * om; const float t1 = xv * ps; xv = t0 + t1; }
-                        a = fmaf(xv, sW[k * JB + jl], a);
+                        for (int k = 0; k < KC; ++k) {
+                            const float t0 = sAvg[k] * om, t1 = xs[k] * ps;
+                            a = fmaf(t0 + t1, sW[k * JB + jl], a);
+                        }
+                    } else {
+#pragma unroll 8
+                        for (int k = 0; k < KC; ++k) a = fmaf(xs[k], sW[k * JB + jl], a);
                     }
                     acc[i] = a;
                 }
