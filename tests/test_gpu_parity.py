@@ -389,6 +389,27 @@ def test_full_size_semantic_tolerance(torch_cuda, gan):
         assert np.abs(f.cpu().numpy() - sf).max() <= 1e-3 * max(1.0, np.abs(sf).max())
 
 
+def test_repeated_calls_are_byte_identical(torch_cuda):
+    """The step exchanges data between workgroups inside kernels (tagged words of the mapping network, 64-bit atomic
+    statistic rows that the finalize kernel clears again): the same inputs must give the same bytes call after call,
+    with another model's calls in between, and after a change of batch size."""
+    import torch
+    from tests.common import pair_digest
+    a = reduced_setup(7, batch=3, seed=4)
+    b = reduced_setup(6, batch=2, seed=6)
+    ga = _build(a[0], a[1], a[2], a[3], 3)
+    gb = _build(b[0], b[1], b[2], b[3], 2)
+    first = {}
+    for it in range(12):
+        for key, gen, st in (("a", ga, a), ("b", gb, b)):
+            n = len(st[4]) if it % 3 else 1                     # every third round a one-sample call in between
+            img, mask = gen.generate_batch(st[4][:n], [x[:n] for x in st[5]])
+            torch.cuda.synchronize()
+            d = pair_digest(img.cpu().numpy(), mask.cpu().numpy())
+            assert first.setdefault((key, n), d) == d, "call %d of model %s (n=%d) differs from the first one" % (it, key, n)
+    assert len(first) == 4
+
+
 def test_two_live_models_do_not_share_state(torch_cuda, oracle_lib):
     """Every Generator / Decoder owns its context (the reference's gluon blocks are independent objects): two models
     of DIFFERENT configurations and two of the same configuration with different weights stay bit-exact against
