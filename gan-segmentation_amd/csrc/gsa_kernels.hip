@@ -1725,6 +1725,12 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 // threads stage block it+1 while block it is multiplied; both halves are at the same channel block in every
 // iteration by construction), and blockIdx.y selects the output-channel group.  A weight block is then read once
 // per two tiles instead of once per tile.
+// LeakyReLU(0.2) on four channels (the scalar lrelu per element)
+__device__ __forceinline__ f32x4 lrelu4(const f32x4& v) {
+    const f32x4 t = v * 0.2f;
+    return f32x4{fmaxf(v[0], t[0]), fmaxf(v[1], t[1]), fmaxf(v[2], t[2]), fmaxf(v[3], t[3])};
+}
+
 template <int NT, int EPI, bool SC, bool BF, int KB, bool WST>
 __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     static_assert(!WST || KB == 1, "streamed weights: one channel block per item");
@@ -1828,17 +1834,23 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
         for (int cbk = 0; cbk < nblk; ++cbk) { load_w(cbk); store_w(cbk); }
     }
     // per-channel epilogue constants: one channel group, so they never change
-    float e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
+    // The MFMAs are issued with the operands SWAPPED (weights as A, pixels as B): D^T, i.e. a lane holds FOUR CONSECUTIVE OUTPUT
+    // CHANNELS (4*(lane>>4) + r) of ONE pixel (lane & 15 -> patch row (lane&15)>>2, column lane&3) -- exactly a 16-byte NHWC
+    // store, no quad transpose (8 DPP moves + 8 selects per accumulator tile).  a*b == b*a and the k order is unchanged: same bits.
+    f32x4 e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = g * 16 * NT + nt * 16 + i16;
-        e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = 0.f;
-        if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
-        if (SC) scb[nt] = p.sc_bias[co];
+        const int co = g * 16 * NT + nt * 16 + 4 * (lane >> 4);
+        e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI == EPI_DEC) {
+            e0[nt] = *reinterpret_cast<const f32x4*>(p.bias + co); e1[nt] = *reinterpret_cast<const f32x4*>(p.bn_rm + co);
+            e2[nt] = *reinterpret_cast<const f32x4*>(p.bn_s + co); e3[nt] = *reinterpret_cast<const f32x4*>(p.bn_beta + co);
+        }
+        if (SC) scb[nt] = *reinterpret_cast<const f32x4*>(p.sc_bias + co);
     }
-    const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;     // quad-transposed store layout
-    const unsigned lane_out = (unsigned)((2 * (lane >> 4) * p.W + 2 * xj) * p.Cout + cq4);
-    const unsigned lane_sc = (unsigned)(((lane >> 4) * p.Ws + xj) * p.Cout + cq4);
+    const int pyl = (lane & 15) >> 2, pxl = lane & 3, cq4 = 4 * (lane >> 4);     // pixel of the 4x4 patch, first channel of the lane
+    const unsigned lane_out = (unsigned)((2 * pyl * p.W + 2 * pxl) * p.Cout + cq4);
+    const unsigned lane_sc = (unsigned)((pyl * p.Ws + pxl) * p.Cout + cq4);
 
     f32x4 ra[KB][4], raff[KB];
 #pragma unroll
@@ -1896,7 +1908,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
                     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
                 } else {
                     f32x4 a[4], b[NT];
 #pragma unroll
@@ -1909,7 +1921,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
                         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][cg], b[nt][cg], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][cg], a[mt][cg], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
@@ -1917,7 +1929,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
             const s16x4 as = *reinterpret_cast<const s16x4*>(a_img + asc);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                accs[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(as, *reinterpret_cast<const s16x4*>(sS + cb * (NT * TS) + bbase + nt * TS), accs[nt], 0, 0, 0);
+                accs[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(sS + cb * (NT * TS) + bbase + nt * TS), as, accs[nt], 0, 0, 0);
         } else if constexpr (SC) {
             const f32x4 as = *reinterpret_cast<const f32x4*>(a_img + asc);
             f32x4 bs[NT];
@@ -1927,7 +1939,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
             for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    accs[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[cg], bs[nt][cg], accs[nt], 0, 0, 0);
+                    accs[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bs[nt][cg], as[cg], accs[nt], 0, 0, 0);
         }
     };
     auto mfma_item = [&](int buf, int ci, int it) {
@@ -1942,24 +1954,18 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[mt][nt][r];
-                    if (EPI == EPI_DEC) {
-                        const float yv = v[r] + e0[nt];
-                        v[r] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
-                    }
+                f32x4 vt = acc[mt][nt];
+                if (EPI == EPI_DEC) {
+                    const f32x4 yv = vt + e0[nt];
+                    vt = lrelu4(__builtin_elementwise_fma(yv - e1[nt], e2[nt], e3[nt]));
                 }
-                const f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
                 const size_t ubase = ((size_t)(t.n * p.H + t.y0 + 8 * (mt >> 1) + py) * p.W + t.x0 + 8 * (mt & 1) + px) * p.Cout + g * 16 * NT + nt * 16;
                 act_store4<BF>(p.out, ubase + lane_out, vt);
                 acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (SC) {
                 const size_t ubase = ((size_t)(t.n * p.Hs + (t.y0 >> 1) + (wave >> 1) * 4) * p.Ws + (t.x0 >> 1) + (wave & 1) * 4) * p.Cout + g * 16 * NT + nt * 16;
-                act_store4<BF>(p.out_sc, ubase + lane_sc,
-                    quad_transpose(accs[nt][0] + scb[nt], accs[nt][1] + scb[nt], accs[nt][2] + scb[nt], accs[nt][3] + scb[nt], xj));
+                act_store4<BF>(p.out_sc, ubase + lane_sc, accs[nt] + scb[nt]);
                 accs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
