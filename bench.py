@@ -196,6 +196,83 @@ def measure_end_to_end(gen, B, steps, dev):
     return out
 
 
+class TimedLoop:
+    """The N-rank control flow of the timed region, free of any GPU call so that a world-size-2 gloo test can drive it
+    with a stub producer (tests/test_abi_and_host.py): per step wait for the slot's previous gather, produce into the
+    slot's send views, submit ONE asynchronous gather (reference image_generator.py:95-114: split over the ctx list +
+    host gather); `fence` = every gather done + barrier + device sync; after warm-up the ranks agree (MAX all-reduce)
+    on the blocking fallback, because the collectives of all ranks must match; `dt` is the MAX over ranks.
+
+    produce(out): write one batch of pairs into out = (img view, mask view); with out=None return (img, mask)."""
+
+    def __init__(self, produce, gat, world, device, allow_blocking, sync=None):
+        self.produce, self.gat, self.world, self.device = produce, gat, world, device
+        self.allow_blocking, self.sync = allow_blocking, sync
+        self.k = 0
+        self.gather = "overlapped" if world > 1 else "none"
+
+    def step(self):
+        from gan_segmentation_amd import dist as gdist
+        slot = self.k % self.gat.depth
+        self.k += 1
+        if self.gather == "blocking":        # fallback (see below): the plain blocking gather
+            gdist.gather_pairs(*self.produce(None))
+            return
+        self.gat.wait(slot)                  # the gather that last read this buffer (`depth` batches ago)
+        self.produce(self.gat.buffers(slot))
+        try:
+            self.gat.submit(slot)
+        except Exception as e:               # an RCCL build without async gather into views
+            if not self.allow_blocking:
+                print("bench: the overlapped gather was refused (%s); rerun with --allow-blocking to time the blocking "
+                      "gather instead" % e, file=sys.stderr, flush=True)
+                raise SystemExit(3)
+            print("bench: overlapped gather failed (%s); using the blocking gather" % e, file=sys.stderr, flush=True)
+            self.gather = "blocking"
+            gdist.gather_pairs(*self.gat.buffers(slot))
+
+    def fence(self):
+        import torch.distributed as dist
+        self.gat.wait_all()
+        if self.world > 1:
+            dist.barrier()
+        if self.sync is not None:
+            self.sync()
+
+    def agree_on_fallback(self):
+        """A rank that fell back during warm-up takes every rank with it (the collectives must match)."""
+        import torch
+        import torch.distributed as dist
+        if self.world > 1:
+            flag = torch.tensor([1 if self.gather == "blocking" else 0], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                self.gather = "blocking"
+
+    def max_over_ranks(self, seconds):
+        import torch
+        import torch.distributed as dist
+        if self.world > 1:
+            t = torch.tensor([seconds], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seconds = float(t.item())
+        return seconds
+
+    def run(self, warmup, steps):
+        t1 = time.perf_counter()
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        self.agree_on_fallback()
+        t_warm = time.perf_counter() - t1
+        t0 = time.perf_counter()
+        for _ in range(steps):               # EXACTLY `steps` steps between two fences
+            self.step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        return {"warmup_s": t_warm, "dt_local": dt, "gather": self.gather, "last_slot": (self.k - 1) % self.gat.depth}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,52 +321,16 @@ def main():
     # the pairs of every rank land on rank 0 through ONE gather per batch, double buffered so that the transfer
     # of batch k overlaps the kernels of batch k+1 (dist.PairGatherer); at N=1 the outputs simply stay in HBM
     gat = gdist.PairGatherer(B, 2 ** mr, gcfg["channels"], device=dev, dst=0, depth=2)
-    state = {"k": 0, "gather": "overlapped" if world > 1 else "none"}
 
-    def step():
-        slot = state["k"] & 1
-        state["k"] += 1
-        if state["gather"] == "blocking":    # fallback (see below): the plain blocking gather
-            gdist.gather_pairs(*gen.generate_batch(z, noise))
-            return
-        gat.wait(slot)                       # the gather that last read this buffer (two batches ago)
-        gen.generate_batch(z, noise, out=gat.buffers(slot))
-        try:
-            gat.submit(slot)
-        except Exception as e:               # an RCCL build without async gather into views
-            if not args.allow_blocking:
-                print("bench: the overlapped gather was refused (%s); rerun with --allow-blocking to time the blocking "
-                      "gather instead" % e, file=sys.stderr, flush=True)
-                raise SystemExit(3)
-            print("bench: overlapped gather failed (%s); using the blocking gather" % e, file=sys.stderr, flush=True)
-            state["gather"] = "blocking"
-            gdist.gather_pairs(*gat.buffers(slot))
+    def produce(out):
+        return gen.generate_batch(z, noise, out=out) if out is not None else gen.generate_batch(z, noise)
 
-    def fence():
-        gat.wait_all()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    loop = TimedLoop(produce, gat, world, dev, args.allow_blocking, sync=torch.cuda.synchronize)
     t_setup = time.perf_counter() - t_proc
-    t1 = time.perf_counter()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    if world > 1:       # a rank that fell back during warm-up takes every rank with it (the collectives must match)
-        flag = torch.tensor([1 if state["gather"] == "blocking" else 0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()):
-            state["gather"] = "blocking"
-    t_warm = time.perf_counter() - t1
     # ---- timed region: EXACTLY K steps (no per-launch events here: 2 event packets around each of the
     # ~130 launches of a step cost ~5 % of the step)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    last_slot = (state["k"] - 1) & 1
+    timing = loop.run(args.warmup, args.steps)
+    t_warm, dt, state, last_slot = timing["warmup_s"], timing["dt_local"], {"gather": timing["gather"]}, timing["last_slot"]
     # ---- roofline pass (untimed): the same K steps with every launch bracketed by HIP events on its
     # stream, and with the decoder/synthesis stream overlap off, so that a kernel's duration is its own
     # and not stretched by the kernel running beside it
@@ -304,10 +345,7 @@ def main():
     ctx.profile_enable(0)
     ctx.set_overlap(-1)        # back to the default (by batch size)
     t_prof = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = loop.max_over_ranks(dt)
 
     if rank == 0:
         pairs = world * B * args.steps

@@ -342,6 +342,107 @@ def test_world_size_4_gatherer_and_generate_shards_on_gloo(tmp_path):
         assert tag in out.stdout, out.stdout[-2000:]
 
 
+_WORKER_BENCH = r"""
+import os, sys
+sys.path.insert(0, ROOT_DIR)
+import numpy as np, torch
+import torch.distributed as dist
+from gan_segmentation_amd import dist as gdist
+import bench
+rank, world, _ = gdist.init_from_env(backend="gloo")
+assert world == 2
+R, ch, B = 8, 3, 2
+
+def pair(r, step, j):      # recognisable bytes per (rank, step, sample): stands in for gsa_generate
+    g = np.random.default_rng(1000 * r + 10 * step + j)
+    return g.integers(0, 256, (R, R, ch), dtype=np.uint8), g.integers(0, 2, (R, R), dtype=np.uint8)
+
+class Stub:
+    def __init__(self): self.calls = 0
+    def __call__(self, out):
+        step = self.calls; self.calls += 1
+        imgs = torch.from_numpy(np.stack([pair(rank, step, j)[0] for j in range(B)]))
+        masks = torch.from_numpy(np.stack([pair(rank, step, j)[1] for j in range(B)]))
+        if out is None:
+            return imgs, masks
+        out[0].copy_(imgs); out[1].copy_(masks)
+        return out
+
+class Refusing(gdist.PairGatherer):       # an RCCL build without async gather into views
+    def __init__(self, *a, who=(0, 1), **k):
+        super().__init__(*a, **k); self.who = who
+    def submit(self, slot):
+        if self.rank in self.who: raise RuntimeError("async gather refused")
+        return super().submit(slot)
+
+# ---- (1) the overlapped path: 2 warm-up + 3 timed steps, content and order of the last batch on rank 0
+stub = Stub()
+gat = gdist.PairGatherer(B, R, ch, device="cpu", dst=0, depth=2)
+loop = bench.TimedLoop(stub, gat, world, "cpu", allow_blocking=False)
+t = loop.run(2, 3)
+assert stub.calls == 5 and t["gather"] == "overlapped" and t["last_slot"] == 0 and t["dt_local"] > 0
+dt = loop.max_over_ranks(float(rank + 1))
+assert dt == 2.0                                                    # MAX over ranks
+if rank == 0:
+    parts = gat.result(t["last_slot"])
+    assert len(parts) == world
+    for r in range(world):
+        for j in range(B):
+            wi, wm = pair(r, 4, j)
+            assert np.array_equal(parts[r][0][j].numpy(), wi) and np.array_equal(parts[r][1][j].numpy(), wm), (r, j)
+    print("BENCH_OVERLAPPED_OK")
+else:
+    assert gat.result(t["last_slot"]) is None
+dist.barrier()
+
+# ---- (2) refusal without --allow-blocking: exit code 3 on the refusing ranks (every rank here)
+loop = bench.TimedLoop(Stub(), Refusing(B, R, ch, device="cpu", dst=0, depth=2), world, "cpu", allow_blocking=False)
+try:
+    loop.run(1, 1)
+    raise AssertionError("refused gather did not stop the run")
+except SystemExit as e:
+    assert e.code == 3
+dist.barrier()
+
+# ---- (3) --allow-blocking, every rank refused: all fall back in the first warm-up step, collectives still match
+loop = bench.TimedLoop(Stub(), Refusing(B, R, ch, device="cpu", dst=0, depth=2), world, "cpu", allow_blocking=True)
+t = loop.run(2, 2)
+assert t["gather"] == "blocking" and loop.gather == "blocking"
+dist.barrier()
+
+# ---- (4) --allow-blocking, ONLY rank 1 refused: rank 0 learns of it from the MAX all-reduce after warm-up
+loop = bench.TimedLoop(Stub(), Refusing(B, R, ch, device="cpu", dst=0, depth=2, who=(1,)), world, "cpu", allow_blocking=True)
+for _ in range(2):
+    loop.step()
+loop.fence()
+assert loop.gather == ("blocking" if rank == 1 else "overlapped")
+loop.agree_on_fallback()
+assert loop.gather == "blocking"                                   # agreed across ranks
+for _ in range(2):
+    loop.step()
+loop.fence()
+if rank == 0:
+    print("BENCH_FALLBACK_OK")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_bench_timed_loop_world_size_2_on_gloo(tmp_path):
+    """bench.py's N>1 control flow (step / fence / fallback flag / MAX reduce) executed on two gloo ranks with a stub
+    producer: the driver's 8-GPU run is then not the first execution of that code (reference image_generator.py:95-114)."""
+    script = tmp_path / "worker_bench.py"
+    script.write_text(_WORKER_BENCH.replace("ROOT_DIR", repr(ROOT)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", "29623", str(script)],
+        capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    for tag in ("BENCH_OVERLAPPED_OK", "BENCH_FALLBACK_OK"):
+        assert tag in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_generate_devices_single_process():
     """One process (the reference's way): the whole GAN_GPU_IDS list is used in-process, the batch is
     GAN_BATCH_SIZE_PER_GPU * len(GAN_GPU_IDS) (reference main.py:87-88); an empty list has no CPU fallback."""
