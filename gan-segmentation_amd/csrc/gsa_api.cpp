@@ -933,7 +933,9 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                         snprintf(layer, sizeof layer, B.is_deconv ? "g.%d.deconv_1" : "g.%d.conv_1", R);
                         static thread_local char kn[128];
                         snprintf(kn, sizeof kn, "%s", subpixel_kernel_name(cp, EPI_RAW, false, n));
-                        Launch lp(c, s, kn, layer, 2.0 * px * C * Cin * 4, 4.0 * (px / 4 * Cin + px * C), B.is_deconv ? -1.0 : 2.0 * px * C * Cin * 9);
+                        // executed: 4 taps per output, or 9 products per 2x2 class outputs in the Winograd F(2x2,2x2) form; algorithmic: the
+                        // reference's operator (16-tap transposed conv = 4 taps per output; 9-tap conv on the upsampled image)
+                        Launch lp(c, s, kn, layer, 2.0 * px * C * Cin * (subpixel_uses_wino(cp) ? 2.25 : 4.0), 4.0 * (px / 4 * Cin + px * C), 2.0 * px * C * Cin * (B.is_deconv ? 4 : 9));
                         HIP_TRY(launch_subpixel(cp, EPI_RAW, false, n, s));
                     } else {
                         cp.up = 1;
@@ -1022,7 +1024,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 if (R2 >= 16) {   // sub-pixel form: 4 taps per output instead of 9
                     static thread_local char kn[128];
                     snprintf(kn, sizeof kn, "%s", subpixel_kernel_name(cp, EPI_DEC, d.has_sc, n));
-                    Launch lp(c, s, kn, layer, 2.0 * px2 * d.cs * d.in_c * 4 + (d.has_sc ? 2.0 * px * d.cs * d.in_c : 0.0),
+                    Launch lp(c, s, kn, layer, 2.0 * px2 * d.cs * d.in_c * (subpixel_uses_wino(cp) ? 2.25 : 4.0) + (d.has_sc ? 2.0 * px * d.cs * d.in_c : 0.0),
                               4.0 * (px * d.in_c + px2 * d.cs + (d.has_sc ? px * d.cs : 0.0)), 2.0 * px2 * d.cs * d.in_c * (9 + (d.has_sc ? 1 : 0)));
                     cp.up = 0;
                     HIP_TRY(launch_subpixel(cp, EPI_DEC, d.has_sc, n, s));

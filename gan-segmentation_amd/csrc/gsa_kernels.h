@@ -74,7 +74,8 @@ hipError_t launch_conv3x3(const ConvParams& p, int epi, bool shortcut, int n, hi
 bool conv_uses_ws(const ConvParams& p, int epi, bool shortcut, int n);
 bool conv_uses_ksplit(const ConvParams& p, bool shortcut);         // true: 4-way K split form (static rule: layer shape only)
 bool conv_uses_wino(const ConvParams& p, int epi, bool shortcut);   // true: Winograd form (static rule: layer shape only)   // true: wave-specialised kernel, no partial rows
-hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);   // deconv4x4s2 / sub-pixel up+conv3x3
+hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);   // deconv4x4s2 / sub-pixel up+conv
+bool subpixel_uses_wino(const ConvParams& p);                      // true: Winograd F(2x2,2x2) form (static rule: fp32 mode): 9 products per 2x2 class outputs instead of 163x3
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s);
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);
 hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_t s);

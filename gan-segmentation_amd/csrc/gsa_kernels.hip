@@ -1499,15 +1499,89 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
 }
 
 // ------------------------------------------------------------------------------------------
+// Winograd F(2x2, 2x2) form of the stride-2 parity-class convolutions (round 3; canonical arithmetic:
+// oracle/c/gsa_oracle.c deconv4x4s2_wino).  A parity class (py, px) of the 4x4 stride-2 transposed
+// convolution is a 2x2-tap stride-1 convolution; per 2x2 class outputs the Winograd form needs 9 products instead of 16:
+//     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A,   B^T = [1 -1 0; 0 1 0; 0 -1 1],  G = [1 0; 1 1; 0 1],  A^T = [1 1 0; 0 1 1]
+// i.e. nine GEMMs M_f[tile][o] = sum_c V_f[tile][c] U_f[c][o] with M = 16 Winograd tiles (the 4x4 grid of 2x2 input blocks of
+// an 8x8 input tile), N = 16 output channels, K = channels: 36 MFMAs per 16-channel block where the direct form issues 64.
+// Every coefficient is +-1, and U = G g G^T is FIVE fp32 adds of the class's four taps (every add rounded: the canonical
+// definition), so the weights in HBM / LDS stay the packed 4x4 kernel -- no second panel, the resident / streamed panel
+// sizes of the direct form hold -- and U is formed in registers per (block, 16 output channels).
+// Lane (i16, kq): Winograd tile (ty, tx) = (2*b0 + b1, 2*b2 + b3) (b = bits of i16): with a row stride of 10*16+4 floats the
+// nine ds_read_b128 of the 3x3 patch are bank-conflict free (brute-forced over the ds_read_b128 lane groups); k slot kq.
+// The MFMAs take the weights as the A operand and the tiles as B (D^T): a lane holds FOUR CONSECUTIVE OUTPUT CHANNELS
+// (4*(lane>>4) + r) of its tile, so after the output transform each of its 2x2 outputs is one 16-byte NHWC store.
+__device__ __forceinline__ int wino22_tile_y(int i16) { return (i16 & 1) * 2 + ((i16 >> 1) & 1); }
+__device__ __forceinline__ int wino22_tile_x(int i16) { return ((i16 >> 2) & 1) * 2 + ((i16 >> 3) & 1); }
+
+// one 16-channel block: ap = the lane's patch origin in the LDS image (row py / column px of its tile's halo patch, k slot
+// included), bp = the block's weights of this lane ([tap16][kq][16][cg] + (kq*16 + i16)*4), SEG = floats per 16 output channels
+template <int NT, int SEG>
+__device__ __forceinline__ void wino22_block(const float* ap, int RS, const float* bp, int py, int px, f32x4 (&acc)[9][NT]) {
+    f32x4 V[9];
+    {
+        f32x4 d[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[r][c] = *reinterpret_cast<const f32x4*>(ap + r * RS + c * 16);
+        // rows t0 = d0 - d1, t1 = d1, t2 = d2 - d1; then the same three forms along the columns
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { d[0][c] = d[0][c] - d[1][c]; d[2][c] = d[2][c] - d[1][c]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { V[3 * r] = d[r][0] - d[r][1]; V[3 * r + 1] = d[r][1]; V[3 * r + 2] = d[r][2] - d[r][1]; }
+    }
+    // taps of the class filter g[a][b] = Wd[3 - py - 2a][3 - px - 2b]
+    const int t00 = ((3 - py) * 4 + (3 - px)) * 256, t01 = ((3 - py) * 4 + (1 - px)) * 256;
+    const int t10 = ((1 - py) * 4 + (3 - px)) * 256, t11 = ((1 - py) * 4 + (1 - px)) * 256;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 U[9];
+        U[0] = *reinterpret_cast<const f32x4*>(bp + nt * SEG + t00);
+        U[2] = *reinterpret_cast<const f32x4*>(bp + nt * SEG + t01);
+        U[6] = *reinterpret_cast<const f32x4*>(bp + nt * SEG + t10);
+        U[8] = *reinterpret_cast<const f32x4*>(bp + nt * SEG + t11);
+        U[1] = U[0] + U[2];
+        U[7] = U[6] + U[8];
+        U[3] = U[0] + U[6];
+        U[5] = U[2] + U[8];
+        U[4] = U[1] + U[7];
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+            for (int f = 0; f < 9; ++f)
+                acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[f][cg], V[f][cg], acc[f][nt], 0, 0, 0);
+    }
+}
+
+// output transform Y = A^T M A of one 16-channel output tile: rows s0 = m0 + m1, s1 = m1 + m2, then along the columns
+__device__ __forceinline__ void wino22_output(const f32x4 (&m)[9], f32x4 (&y)[2][2]) {
+    f32x4 s0[3], s1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { s0[j] = m[j] + m[3 + j]; s1[j] = m[3 + j] + m[6 + j]; }
+    y[0][0] = s0[0] + s0[1]; y[0][1] = s0[1] + s0[2];
+    y[1][0] = s1[0] + s1[1]; y[1][1] = s1[1] + s1[2];
+}
+
+// LeakyReLU(0.2) on four channels (the scalar lrelu per element)
+__device__ __forceinline__ f32x4 lrelu4(const f32x4& v) {
+    const f32x4 t = v * 0.2f;
+    return f32x4{fmaxf(v[0], t[0]), fmaxf(v[1], t[1]), fmaxf(v[2], t[2]), fmaxf(v[3], t[3])};
+}
+
+// ------------------------------------------------------------------------------------------
 // Stride-2 "parity class" convolution: Deconvolution 4x4 s2 p1 (the reference's fused upscale)
 // AND nearest-x2 + conv3x3 in its sub-pixel form (weights pre-summed on the host into the same
 // 4x4 stride-2 kernel: 2.25x fewer MACs than 9 taps on the upsampled image).
 // A 16x16 output tile splits into 4 parity classes (oy&1, ox&1); each is a 2x2-tap convolution
 // over the 10x10 input tile with its own weights.  One wave per class, 4 patches of 4x4 outputs.
-template <int NT, int EPI, bool SC, bool BF>
+template <int NT, int EPI, bool SC, bool BF, bool WINO = false>
 __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
+    static_assert(!(WINO && BF), "the Winograd form is fp32 only");
     constexpr int PX = BF ? 8 : 16, TS = BF ? 128 : 256, KQ = BF ? 2 : 4;     // 4-byte slots, as in conv3x3_mfma
-    constexpr int LH = 10, LW = 10, RS = LW * PX + (BF ? 4 : 8);
+    constexpr int LH = 10, LW = 10, RS = LW * PX + (BF || WINO ? 4 : 8);     // WINO: conflict-free 3x3 patch reads at stride-2 tiles
+    constexpr int NA = WINO ? 9 : 4;                  // accumulator tiles per 16 output channels: frequencies / 4x4 patches
     constexpr int COUT_T = 16 * NT, SEG = 16 * TS, NB4 = NT * SEG / 4, BIT = (NB4 + 255) / 256;
     constexpr int SIT = (NT * TS / 4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1545,10 +1619,13 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
     // (the consumer reads it with resid_up).  The 8x8 input pixels of the tile are 4 patches; wave w
     // takes patch w (A operand = the offset-(0,0) tap of that patch).
     const int asc = ((wave >> 1) * 4 + (i16 >> 2) + 1) * RS + ((wave & 1) * 4 + (i16 & 3) + 1) * PX + kq * KQ;
-    f32x4 acc[4][NT];
+    // WINO: the lane's 3x3 patch (halo coordinates) of Winograd tile (wty, wtx), shifted by the class
+    const int wty = wino22_tile_y(i16), wtx = wino22_tile_x(i16);
+    const int pbase = (2 * wty + py) * RS + (2 * wtx + px) * 16 + kq * 4;
+    f32x4 acc[NA][NT];
     f32x4 accs[SC ? NT : 1];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < NA; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (SC) {
@@ -1605,6 +1682,9 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 #ifdef GSA_DBG_HOOKS
         if (!(p.dbg & 16)) {
 #endif
+        if constexpr (WINO) {
+            wino22_block<NT, SEG>(sA + pbase, RS, sB + bbase, py, px, acc);
+        } else {
 #pragma unroll
         for (int jy = 0; jy < 2; ++jy) {
             const int ky = (py ? 0 : 1) + 2 * jy;
@@ -1642,6 +1722,7 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
                 }
             }
         }
+        }
 #ifdef GSA_DBG_HOOKS
         }
 #endif
@@ -1671,6 +1752,33 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
             __syncthreads();
         }
     }
+    if constexpr (WINO) {
+        // transposed accumulators: lane = (tile i16, output channels 4*(lane>>4)..+3); each of the tile's 2x2 class outputs is one
+        // 16-byte NHWC store
+        const int cq = 4 * (lane >> 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = g * COUT_T + nt * 16 + cq;
+            f32x4 m[9], y[2][2];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) m[f] = acc[f][nt];
+            wino22_output(m, y);
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+            if (EPI == EPI_DEC) {
+                c0 = *reinterpret_cast<const f32x4*>(p.bias + co); c1 = *reinterpret_cast<const f32x4*>(p.bn_rm + co);
+                c2 = *reinterpret_cast<const f32x4*>(p.bn_s + co); c3 = *reinterpret_cast<const f32x4*>(p.bn_beta + co);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x4 vt = y[a][b];
+                    if (EPI == EPI_DEC) vt = lrelu4(__builtin_elementwise_fma((vt + c0) - c1, c2, c3));
+                    const int oy = y0 + 2 * (2 * wty + a) + py, ox = x0 + 2 * (2 * wtx + b) + px;
+                    act_store4<false>(p.out, ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + co, vt);
+                }
+        }
+    }
     float e0[NT], e1[NT], e2[NT], e3[NT], scb[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1684,6 +1792,7 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int cot = g * COUT_T + nt * 16 + cq4;
+        if constexpr (!WINO) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int oy = y0 + 2 * ((mt >> 1) * 4 + (lane >> 4)) + py;
@@ -1702,6 +1811,7 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
             if (!(p.dbg & 4))
 #endif
             act_store4<BF>(p.out, ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + cot, vt);
+        }
         }
         if (SC) {
             const int iy = y0 / 2 + (wave >> 1) * 4 + (lane >> 4);
@@ -1725,17 +1835,13 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 // threads stage block it+1 while block it is multiplied; both halves are at the same channel block in every
 // iteration by construction), and blockIdx.y selects the output-channel group.  A weight block is then read once
 // per two tiles instead of once per tile.
-// LeakyReLU(0.2) on four channels (the scalar lrelu per element)
-__device__ __forceinline__ f32x4 lrelu4(const f32x4& v) {
-    const f32x4 t = v * 0.2f;
-    return f32x4{fmaxf(v[0], t[0]), fmaxf(v[1], t[1]), fmaxf(v[2], t[2]), fmaxf(v[3], t[3])};
-}
-
-template <int NT, int EPI, bool SC, bool BF, int KB, bool WST>
+template <int NT, int EPI, bool SC, bool BF, int KB, bool WST, bool WINO = false>
 __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     static_assert(!WST || KB == 1, "streamed weights: one channel block per item");
+    static_assert(!(WINO && BF), "the Winograd form is fp32 only");
     constexpr int PX = BF ? 8 : 16, TS = BF ? 128 : 256, KQ = BF ? 2 : 4;
-    constexpr int LH = 10, LW = 10, RS = LW * PX + (BF ? 4 : 8);
+    constexpr int LH = 10, LW = 10, RS = LW * PX + (BF || WINO ? 4 : 8);     // WINO: conflict-free 3x3 patch reads at stride-2 tiles
+    constexpr int NA = WINO ? 9 : 4;                  // accumulator tiles per 16 output channels: frequencies / 4x4 patches
     constexpr int SEG = 16 * TS, NB4 = NT * SEG / 4, BIT = (NB4 + 511) / 512;
     constexpr int SIT = (NT * TS / 4 + 511) / 512;
     const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4;
@@ -1789,10 +1895,12 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
         abase[mt] = ((mt >> 1) * 4 + (i16 >> 2) + 1) * RS + ((mt & 1) * 4 + (i16 & 3) + 1) * PX + kq * KQ;
     const int bbase = (kq * 16 + i16) * KQ;
     const int asc = ((wave >> 1) * 4 + (i16 >> 2) + 1) * RS + ((wave & 1) * 4 + (i16 & 3) + 1) * PX + kq * KQ;
-    f32x4 acc[4][NT];
+    const int wty = wino22_tile_y(i16), wtx = wino22_tile_x(i16);       // WINO: the lane's Winograd tile; its 3x3 patch shifted by the class
+    const int pbase = (2 * wty + py) * RS + (2 * wtx + px) * 16 + kq * 4;
+    f32x4 acc[NA][NT];
     f32x4 accs[SC ? NT : 1];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < NA; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (SC) {
@@ -1849,7 +1957,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
         if (SC) scb[nt] = *reinterpret_cast<const f32x4*>(p.sc_bias + co);
     }
     const int pyl = (lane & 15) >> 2, pxl = lane & 3, cq4 = 4 * (lane >> 4);     // pixel of the 4x4 patch, first channel of the lane
-    const unsigned lane_out = (unsigned)((2 * pyl * p.W + 2 * pxl) * p.Cout + cq4);
+    const unsigned lane_out = WINO ? (unsigned)((4 * wty * p.W + 4 * wtx) * p.Cout + cq4) : (unsigned)((2 * pyl * p.W + 2 * pxl) * p.Cout + cq4);
     const unsigned lane_sc = (unsigned)((pyl * p.Ws + pxl) * p.Cout + cq4);
 
     f32x4 ra[KB][4], raff[KB];
@@ -1888,6 +1996,9 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
         const float* b_img = sW + cb * (NT * SEG);
         // valid taps of this parity class, ascending ky then kx:
         //   py==0: ky=1 (dy 0), ky=3 (dy -1);   py==1: ky=0 (dy +1), ky=2 (dy 0)
+        if constexpr (WINO) {
+            wino22_block<NT, SEG>(a_img + pbase, RS, b_img + bbase, py, px, acc);
+        } else {
 #pragma unroll
         for (int jy = 0; jy < 2; ++jy) {
             const int ky = (py ? 0 : 1) + 2 * jy;
@@ -1925,6 +2036,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
                 }
             }
         }
+        }
         if constexpr (SC && BF) {
             const s16x4 as = *reinterpret_cast<const s16x4*>(a_img + asc);
 #pragma unroll
@@ -1952,6 +2064,22 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     auto epilogue = [&](const Tile& t) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (WINO) {
+                f32x4 m[9], y[2][2];
+#pragma unroll
+                for (int f = 0; f < 9; ++f) { m[f] = acc[f][nt]; acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                wino22_output(m, y);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {       // the tile's 2x2 class outputs (a, b) = (mt >> 1, mt & 1)
+                    f32x4 vt = y[mt >> 1][mt & 1];
+                    if (EPI == EPI_DEC) {
+                        const f32x4 yv = vt + e0[nt];
+                        vt = lrelu4(__builtin_elementwise_fma(yv - e1[nt], e2[nt], e3[nt]));
+                    }
+                    const size_t ubase = ((size_t)(t.n * p.H + t.y0 + 2 * (mt >> 1) + py) * p.W + t.x0 + 2 * (mt & 1) + px) * p.Cout + g * 16 * NT + nt * 16;
+                    act_store4<false>(p.out, ubase + lane_out, vt);
+                }
+            } else {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 f32x4 vt = acc[mt][nt];
@@ -1962,6 +2090,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
                 const size_t ubase = ((size_t)(t.n * p.H + t.y0 + 8 * (mt >> 1) + py) * p.W + t.x0 + 8 * (mt & 1) + px) * p.Cout + g * 16 * NT + nt * 16;
                 act_store4<BF>(p.out, ubase + lane_out, vt);
                 acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             }
             if (SC) {
                 const size_t ubase = ((size_t)(t.n * p.Hs + (t.y0 >> 1) + (wave >> 1) * 4) * p.Ws + (t.x0 >> 1) + (wave & 1) * 4) * p.Cout + g * 16 * NT + nt * 16;
@@ -3195,11 +3324,20 @@ hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStrea
     return hipErrorInvalidValue;
 }
 
-template <int NT, int EPI, bool SC, bool BF>
+// Winograd F(2x2,2x2) form of the stride-2 layers: every such layer in fp32 mode (the static rule of the canonical arithmetic,
+// oracle/c/gsa_oracle.c use_wino22).  GSA_WINO22=0 selects the direct 4-tap kernels -- a different arithmetic, timing only.
+static bool sub_wino(const ConvParams& p) {
+    static const bool enabled = !(getenv("GSA_WINO22") && atoi(getenv("GSA_WINO22")) == 0);
+    return enabled && !p.bf16;
+}
+bool subpixel_uses_wino(const ConvParams& p) { return sub_wino(p); }
+static int sub_rs(const ConvParams& p) { return p.bf16 ? 10 * 8 + 4 : 10 * 16 + (sub_wino(p) ? 4 : 8); }      // LDS row stride in 4-byte slots
+
+template <int NT, int EPI, bool SC, bool BF, bool WINO = false>
 static hipError_t launch_subpixel_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int COUT_T = 16 * NT, TS = BF ? 128 : 256;
-    const size_t lds = sizeof(float) * (10 * (10 * (BF ? 8 : 16) + (BF ? 4 : 8)) + NT * 16 * TS + (SC ? NT * TS : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
-    auto kern = subpixel_mfma<NT, EPI, SC, BF>;
+    const size_t lds = sizeof(float) * (10 * (10 * (BF ? 8 : 16) + (BF || WINO ? 4 : 8)) + NT * 16 * TS + (SC ? NT * TS : 0)) + (p.aff0 ? sizeof(float4) * p.C0 : 0);
+    auto kern = subpixel_mfma<NT, EPI, SC, BF, WINO>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
     {
@@ -3218,9 +3356,9 @@ static hipError_t launch_subpixel_t(const ConvParams& p, int n, hipStream_t s) {
 static int subpixel_res_kb(const ConvParams& p);
 
 // persistent form with the LDS-resident weight panel (subpixel_res): one 512-thread workgroup per CU
-template <int NT, int EPI, bool SC, bool BF, int KB>
+template <int NT, int EPI, bool SC, bool BF, int KB, bool WINO>
 static hipError_t launch_subpixel_res_k(const ConvParams& p, int n, size_t lds, hipStream_t s) {
-    auto kern = subpixel_res<NT, EPI, SC, BF, KB, false>;
+    auto kern = subpixel_res<NT, EPI, SC, BF, KB, false, WINO>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
     int num_cus = 0;
@@ -3241,9 +3379,9 @@ static hipError_t launch_subpixel_res_k(const ConvParams& p, int n, size_t lds, 
 }
 
 // streamed-weights form: grid (workgroups per channel group, channel groups)
-template <int NT, int EPI, bool SC, bool BF>
+template <int NT, int EPI, bool SC, bool BF, bool WINO = false>
 static hipError_t launch_subpixel_wst_t(const ConvParams& p, int n, size_t lds, int wgs_per_g, hipStream_t s) {
-    auto kern = subpixel_res<NT, EPI, SC, BF, 1, true>;
+    auto kern = subpixel_res<NT, EPI, SC, BF, 1, true, WINO>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
     {
@@ -3269,7 +3407,7 @@ static size_t subpixel_wst_lds(const ConvParams& p, int ct, bool sc, int n, int*
         num_cus = device_cus(p.device);
     }
     if (!enabled || p.Cout % ct) return 0;
-    const int ts = p.bf16 ? 128 : 256, px = p.bf16 ? 8 : 16, rs = 10 * px + (p.bf16 ? 4 : 8);
+    const int ts = p.bf16 ? 128 : 256, rs = sub_rs(p);
     const int nt = ct / 16, groups = p.Cout / ct;
     const size_t lds = sizeof(float) * ((size_t)2 * nt * 16 * ts + (sc ? (size_t)2 * nt * ts : 0) + 4 * 10 * rs) + 64 * sizeof(float4);
     const long tiles = (long)(p.H / 16) * (p.W / 16) * n;
@@ -3279,10 +3417,10 @@ static size_t subpixel_wst_lds(const ConvParams& p, int ct, bool sc, int n, int*
     return lds;
 }
 
-template <int NT, int EPI, bool SC, bool BF>
+template <int NT, int EPI, bool SC, bool BF, bool WINO = false>
 static hipError_t launch_subpixel_res_t(const ConvParams& p, int n, size_t lds, hipStream_t s) {
-    return subpixel_res_kb(p) == 2 ? launch_subpixel_res_k<NT, EPI, SC, BF, 2>(p, n, lds, s)
-                                   : launch_subpixel_res_k<NT, EPI, SC, BF, 1>(p, n, lds, s);
+    return subpixel_res_kb(p) == 2 ? launch_subpixel_res_k<NT, EPI, SC, BF, 2, WINO>(p, n, lds, s)
+                                   : launch_subpixel_res_k<NT, EPI, SC, BF, 1, WINO>(p, n, lds, s);
 }
 
 // LDS bytes of subpixel_res for this layer, or 0 when the layer does not qualify (several channel groups, a
@@ -3290,7 +3428,7 @@ static hipError_t launch_subpixel_res_t(const ConvParams& p, int n, size_t lds, 
 static size_t subpixel_res_lds(const ConvParams& p, int ct, bool sc, int n) {
     static const bool enabled = !(getenv("GSA_SUBRES") && atoi(getenv("GSA_SUBRES")) == 0);
     if (!enabled || ct != p.Cout || ct > 32) return 0;      // instantiated for 16 and 32 output channels
-    const int ts = p.bf16 ? 128 : 256, px = p.bf16 ? 8 : 16, rs = 10 * px + (p.bf16 ? 4 : 8);
+    const int ts = p.bf16 ? 128 : 256, rs = sub_rs(p);
     const int nblk = (p.C0 + p.C1) / 16, nt = ct / 16;
     const size_t fixed = sizeof(float) * ((size_t)nblk * nt * 16 * ts + (sc ? (size_t)nblk * nt * ts : 0));
     const long tiles = (long)(p.H / 16) * (p.W / 16) * n;
@@ -3303,7 +3441,7 @@ static size_t subpixel_res_lds(const ConvParams& p, int ct, bool sc, int n) {
 }
 
 static int subpixel_res_kb(const ConvParams& p) {
-    const int ts = p.bf16 ? 128 : 256, px = p.bf16 ? 8 : 16, rs = 10 * px + (p.bf16 ? 4 : 8);
+    const int ts = p.bf16 ? 128 : 256, rs = sub_rs(p);
     const int nblk = (p.C0 + p.C1) / 16, nt = p.Cout / 16;
     const bool sc = p.wsc != nullptr;
     const size_t fixed = sizeof(float) * ((size_t)nblk * nt * 16 * ts + (sc ? (size_t)nblk * nt * ts : 0));
@@ -3312,34 +3450,35 @@ static int subpixel_res_kb(const ConvParams& p) {
 }
 
 // widest channel tile that still gives the chip >= 2 workgroups per CU (else the narrowest)
-static int subpixel_cout_tile(int H, int W, int Cout, int n) {
+static int subpixel_cout_tile(int H, int W, int Cout, int n, bool wino = false) {
     const long tiles = (long)(H / 16) * (W / 16) * n;
-    for (int ct = 64; ct >= 16; ct /= 2)
+    for (int ct = wino ? 32 : 64; ct >= 16; ct /= 2)      // Winograd form: nine accumulator vectors per 16 channels -- at most 32 per workgroup
         if (Cout % ct == 0 && (tiles * (Cout / ct) >= 512 || ct == 16)) return ct;
     return 16;
 }
 
 // exact C++ name of the instantiation launch_subpixel picks (profile labels)
 const char* subpixel_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
-    static thread_local char buf[112];
-    const int ct = subpixel_cout_tile(p.H, p.W, p.Cout, n);
+    static thread_local char buf[128];
+    const char* wn = sub_wino(p) ? "true" : "false";
+    const int ct = subpixel_cout_tile(p.H, p.W, p.Cout, n, sub_wino(p));
     const bool res = subpixel_res_lds(p, ct, sc, n) != 0;
     int wgs_per_g = 0;
     if (res)
-        snprintf(buf, sizeof buf, "void gsa::subpixel_res<%d, %d, %s, %s, %d, false>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
-                 p.bf16 ? "true" : "false", subpixel_res_kb(p));
+        snprintf(buf, sizeof buf, "void gsa::subpixel_res<%d, %d, %s, %s, %d, false, %s>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
+                 p.bf16 ? "true" : "false", subpixel_res_kb(p), wn);
     else if (subpixel_wst_lds(p, ct, sc, n, &wgs_per_g))
-        snprintf(buf, sizeof buf, "void gsa::subpixel_res<%d, %d, %s, %s, 1, true>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
-                 p.bf16 ? "true" : "false");
+        snprintf(buf, sizeof buf, "void gsa::subpixel_res<%d, %d, %s, %s, 1, true, %s>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
+                 p.bf16 ? "true" : "false", wn);
     else
-        snprintf(buf, sizeof buf, "void gsa::subpixel_mfma<%d, %d, %s, %s>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
-                 p.bf16 ? "true" : "false");
+        snprintf(buf, sizeof buf, "void gsa::subpixel_mfma<%d, %d, %s, %s, %s>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
+                 p.bf16 ? "true" : "false", wn);
     return buf;
 }
 
 const char* subpixel_geom_name(int H, int W, int Cout, int n) {
     static thread_local char buf[32];
-    snprintf(buf, sizeof buf, "%d", subpixel_cout_tile(H, W, Cout, n) / 16);   // NT
+    snprintf(buf, sizeof buf, "%d", subpixel_cout_tile(H, W, Cout, n) / 16);   // NT (direct form)
     return buf;
 }
 
@@ -3347,31 +3486,40 @@ const char* subpixel_geom_name(int H, int W, int Cout, int n) {
 hipError_t launch_subpixel(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     if (p.H != 2 * p.Hs || p.W != 2 * p.Ws || p.H % 16 || p.W % 16 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
     if (sc && epi != EPI_DEC) return hipErrorInvalidValue;
-    const int ct = subpixel_cout_tile(p.H, p.W, p.Cout, n);
+    const bool wino = sub_wino(p);
+    const int ct = subpixel_cout_tile(p.H, p.W, p.Cout, n, wino);
     if (const size_t rlds = subpixel_res_lds(p, ct, sc, n)) {
-#define GSA_SUBR(NT, BF) \
-        if (ct == 16 * NT && (p.bf16 != 0) == BF) { \
-            if (sc) return launch_subpixel_res_t<NT, EPI_DEC, true, BF>(p, n, rlds, s); \
-            if (epi == EPI_DEC) return launch_subpixel_res_t<NT, EPI_DEC, false, BF>(p, n, rlds, s); \
-            if (epi == EPI_RAW) return launch_subpixel_res_t<NT, EPI_RAW, false, BF>(p, n, rlds, s); \
+#define GSA_SUBR(NT, BF, WN) \
+        if (ct == 16 * NT && (p.bf16 != 0) == BF && wino == WN) { \
+            if (sc) return launch_subpixel_res_t<NT, EPI_DEC, true, BF, WN>(p, n, rlds, s); \
+            if (epi == EPI_DEC) return launch_subpixel_res_t<NT, EPI_DEC, false, BF, WN>(p, n, rlds, s); \
+            if (epi == EPI_RAW) return launch_subpixel_res_t<NT, EPI_RAW, false, BF, WN>(p, n, rlds, s); \
             return hipErrorInvalidValue; \
         }
-        GSA_SUBR(1, false) GSA_SUBR(2, false) GSA_SUBR(1, true) GSA_SUBR(2, true)
+        GSA_SUBR(1, false, false) GSA_SUBR(2, false, false) GSA_SUBR(1, true, false) GSA_SUBR(2, true, false)
+        GSA_SUBR(1, false, true) GSA_SUBR(2, false, true)
 #undef GSA_SUBR
     }
     int wgs_per_g = 0;
     if (const size_t wlds = subpixel_wst_lds(p, ct, sc, n, &wgs_per_g)) {
-#define GSA_SUBW(NT, BF) \
-        if (ct == 16 * NT && (p.bf16 != 0) == BF) { \
-            if (sc) return launch_subpixel_wst_t<NT, EPI_DEC, true, BF>(p, n, wlds, wgs_per_g, s); \
-            if (epi == EPI_DEC) return launch_subpixel_wst_t<NT, EPI_DEC, false, BF>(p, n, wlds, wgs_per_g, s); \
-            if (epi == EPI_RAW) return launch_subpixel_wst_t<NT, EPI_RAW, false, BF>(p, n, wlds, wgs_per_g, s); \
+#define GSA_SUBW(NT, BF, WN) \
+        if (ct == 16 * NT && (p.bf16 != 0) == BF && wino == WN) { \
+            if (sc) return launch_subpixel_wst_t<NT, EPI_DEC, true, BF, WN>(p, n, wlds, wgs_per_g, s); \
+            if (epi == EPI_DEC) return launch_subpixel_wst_t<NT, EPI_DEC, false, BF, WN>(p, n, wlds, wgs_per_g, s); \
+            if (epi == EPI_RAW) return launch_subpixel_wst_t<NT, EPI_RAW, false, BF, WN>(p, n, wlds, wgs_per_g, s); \
             return hipErrorInvalidValue; \
         }
-        GSA_SUBW(1, false) GSA_SUBW(2, false) GSA_SUBW(4, false) GSA_SUBW(1, true) GSA_SUBW(2, true) GSA_SUBW(4, true)
+        GSA_SUBW(1, false, false) GSA_SUBW(2, false, false) GSA_SUBW(4, false, false) GSA_SUBW(1, true, false) GSA_SUBW(2, true, false) GSA_SUBW(4, true, false)
+        GSA_SUBW(1, false, true) GSA_SUBW(2, false, true)
 #undef GSA_SUBW
     }
 #define GSA_SUB(NT) \
+    if (ct == 16 * NT && wino && NT <= 2) { \
+        if (sc) return launch_subpixel_t<(NT <= 2 ? NT : 1), EPI_DEC, true, false, true>(p, n, s); \
+        if (epi == EPI_DEC) return launch_subpixel_t<(NT <= 2 ? NT : 1), EPI_DEC, false, false, true>(p, n, s); \
+        if (epi == EPI_RAW) return launch_subpixel_t<(NT <= 2 ? NT : 1), EPI_RAW, false, false, true>(p, n, s); \
+        return hipErrorInvalidValue; \
+    } \
     if (ct == 16 * NT && !p.bf16) { \
         if (sc) return launch_subpixel_t<NT, EPI_DEC, true, false>(p, n, s); \
         if (epi == EPI_DEC) return launch_subpixel_t<NT, EPI_DEC, false, false>(p, n, s); \

@@ -672,6 +672,96 @@ static void deconv4x4s2(const float* in, int Hs, int Ws, int Cin, const float* W
             }
 }
 
+/* ---- Winograd F(2x2, 2x2) form of the stride-2 layers (round 3) --------------------------------------------------
+ * Rule (static, by mode only): in fp32 mode EVERY layer evaluated in the stride-2 form -- Deconvolution k4 s2 p1
+ * (reference networks_stylegan.py:460-476) and nearest-x2 + conv3x3 with outputs >= 16 px (the pre-summed 4x4 kernel of
+ * pack_upconv; reference :22-27, networks_seg.py:86-88) -- is evaluated per output parity class (py, px) as a 2x2-tap
+ * stride-1 convolution in Winograd F(2x2, 2x2) form: 9 products per 2x2 class outputs instead of 16.
+ *   class filter   g[a][b] = Wd[ky(a)][kx(b)],  ky(a) = 3 - py - 2a,  kx(b) = 3 - px - 2b   (a, b = 0: the input row /
+ *                  column i - 1 + py, 1: the next one);  y[i] = g0 d[i-1+py] + g1 d[i+py]
+ *   weights        U = G g G^T in fp32, every add rounded:  u01 = g00+g01, u21 = g10+g11, u10 = g00+g10, u12 = g01+g11,
+ *                  u11 = u01 + u21, the corners are the taps themselves
+ *   input          per tile (2x2 class outputs = input rows / columns 2t-1+py .. 2t+1+py, zero outside the image):
+ *                  rows t0 = d0 - d1, t1 = d1, t2 = d2 - d1, then the same three forms along the columns
+ *   products       M[f] = fmaf chain over the input channels (16-channel blocks ascending, CPERM order inside), one chain
+ *                  per frequency f = 3r + c -- bitwise what v_mfma_f32_16x16x4_f32 produces
+ *   output         rows s0 = m0 + m1, s1 = m1 + m2, then the same two forms along the columns.
+ * Exact algebra; the result differs from the 4-tap chain by a few fp32 ulps (oracle/ref_semantic.py keeps the
+ * reference's operators and bounds the difference).  GSAO_WINO22=0 selects the direct form (A/B timing only). */
+static int g_wino22_enabled = -1;
+static int use_wino22(int bf) {
+    if (g_wino22_enabled < 0) { const char* e = getenv("GSAO_WINO22"); g_wino22_enabled = !(e && atoi(e) == 0); }
+    return g_wino22_enabled && !bf;
+}
+
+static void deconv4x4s2_wino(const float* in, int Hs, int Ws, int Cin, const float* Wd, int Cout, float* out) {
+    const int W = Ws * 2;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int ty = 0; ty < Hs / 2; ++ty) {
+        float* V = (float*)malloc(sizeof(float) * 9 * (size_t)Cin);       /* [f][c] of the current (tile, class) */
+        for (int tx = 0; tx < Ws / 2; ++tx)
+            for (int cls = 0; cls < 4; ++cls) {
+                const int py = cls >> 1, px = cls & 1;
+                for (int c = 0; c < Cin; ++c) {
+                    float d[3][3], t[3][3];
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) {
+                            const int yy = 2 * ty - 1 + py + i, xx = 2 * tx - 1 + px + j;
+                            d[i][j] = (yy < 0 || yy >= Hs || xx < 0 || xx >= Ws) ? 0.0f : in[((size_t)yy * Ws + xx) * Cin + c];
+                        }
+                    for (int j = 0; j < 3; ++j) {
+                        t[0][j] = d[0][j] - d[1][j];
+                        t[1][j] = d[1][j];
+                        t[2][j] = d[2][j] - d[1][j];
+                    }
+                    for (int i = 0; i < 3; ++i) {
+                        V[(i * 3 + 0) * Cin + c] = t[i][0] - t[i][1];
+                        V[(i * 3 + 1) * Cin + c] = t[i][1];
+                        V[(i * 3 + 2) * Cin + c] = t[i][2] - t[i][1];
+                    }
+                }
+                const int k0y = 3 - py, k1y = 1 - py, k0x = 3 - px, k1x = 1 - px;     /* taps of g[a][b] */
+                for (int o0 = 0; o0 < Cout; o0 += OC) {
+                    const int on = Cout - o0 < OC ? Cout - o0 : OC;
+                    float M[9][OC];
+                    for (int f = 0; f < 9; ++f)
+                        for (int o = 0; o < OC; ++o) M[f][o] = 0.0f;
+                    for (int cb = 0; cb < Cin / CB; ++cb)
+                        for (int kk = 0; kk < CB; ++kk) {
+                            const int ci = CPERM(kk);
+                            const float* g00 = Wd + (((size_t)cb * 16 + k0y * 4 + k0x) * CB + ci) * Cout + o0;
+                            const float* g01 = Wd + (((size_t)cb * 16 + k0y * 4 + k1x) * CB + ci) * Cout + o0;
+                            const float* g10 = Wd + (((size_t)cb * 16 + k1y * 4 + k0x) * CB + ci) * Cout + o0;
+                            const float* g11 = Wd + (((size_t)cb * 16 + k1y * 4 + k1x) * CB + ci) * Cout + o0;
+                            for (int o = 0; o < on; ++o) {
+                                float u[9];
+                                u[0] = g00[o]; u[2] = g01[o]; u[6] = g10[o]; u[8] = g11[o];
+                                u[1] = g00[o] + g01[o];
+                                u[7] = g10[o] + g11[o];
+                                u[3] = g00[o] + g10[o];
+                                u[5] = g01[o] + g11[o];
+                                u[4] = u[1] + u[7];
+                                for (int f = 0; f < 9; ++f) M[f][o] = fmaf(V[f * Cin + cb * CB + ci], u[f], M[f][o]);
+                            }
+                        }
+                    for (int o = 0; o < on; ++o) {
+                        float sr[2][3];
+                        for (int j = 0; j < 3; ++j) {
+                            sr[0][j] = M[0 + j][o] + M[3 + j][o];
+                            sr[1][j] = M[3 + j][o] + M[6 + j][o];
+                        }
+                        for (int i = 0; i < 2; ++i) {
+                            const size_t row = (size_t)(2 * (2 * ty + i) + py) * W;
+                            out[(row + 2 * (2 * tx) + px) * Cout + o0 + o] = sr[i][0] + sr[i][1];
+                            out[(row + 2 * (2 * tx + 1) + px) * Cout + o0 + o] = sr[i][1] + sr[i][2];
+                        }
+                    }
+                }
+            }
+        free(V);
+    }
+}
+
 /* 3x3 conv, pad 1, NHWC, Winograd F(2x2,3x3) form (see pack_wino).  in: [H][W][Cin] affine-applied; U packed. */
 static void conv3x3_wino(const float* in, int H, int W, int Cin, const float* U, int Cout, float* out) {
 #pragma omp parallel for schedule(dynamic, 1)
@@ -833,7 +923,8 @@ GSAO_API int gsao_generator_forward(gsao_ctx* c, void* stream, int32_t n, const 
                         memcpy(xa, c->constant, sizeof(float) * npix * C); /* broadcast const, reference :178 */
                     } else {
                         /* xb holds the affine-applied previous feature */
-                        if (B->is_deconv) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc, c->bf16);
+                        if ((B->is_deconv || R >= 16) && use_wino22(c->bf16)) deconv4x4s2_wino(xb, R / 2, R / 2, Cin, B->w1, C, xc);
+                        else if (B->is_deconv) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc, c->bf16);
                         else if (R >= 16) deconv4x4s2(xb, R / 2, R / 2, Cin, B->w1, C, xc, c->bf16);   /* sub-pixel up+conv */
                         else conv3x3(xb, R / 2, R / 2, Cin, 1, B->w1, C, xc, c->bf16, 1);
                         store_bf16(xc, npix * C, c->bf16);      /* the raw conv_1 output is a stored tensor */
@@ -1025,7 +1116,8 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                 /* main_block: nearest x2 -> DecoderResBlock, reference :7-46, :86-88 */
                 const int R2 = 2 * R;
                 const size_t np2 = (size_t)R2 * R2;
-                if (R2 >= 16) deconv4x4s2(cat, R, R, d->in_c, d->a_w, d->cs, ya, c->bf16);   /* sub-pixel up+conv */
+                if (R2 >= 16 && use_wino22(c->bf16)) deconv4x4s2_wino(cat, R, R, d->in_c, d->a_w, d->cs, ya);
+                else if (R2 >= 16) deconv4x4s2(cat, R, R, d->in_c, d->a_w, d->cs, ya, c->bf16);   /* sub-pixel up+conv */
                 else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya, c->bf16, 1);
                 bias_bn_act(ya, np2, d->cs, d->a_b, d->a_s, d->a_rm, d->a_beta);
                 store_bf16(ya, np2 * d->cs, c->bf16);
