@@ -448,7 +448,7 @@ struct Launch {
     }
     ~Launch() {
 #ifdef GSA_STAMP
-        if (c->stamps && label && strstr(kname, "conv")) {   // diagnostic build: per-phase wave-cycle sums
+        if (c->stamps && label && (strstr(kname, "conv") || strstr(kname, "subpixel"))) {   // diagnostic build: per-phase wave-cycle sums
             (void)hipStreamSynchronize(s);
             unsigned long long h[16];
             (void)hipMemcpy(h, c->stamps, sizeof h, hipMemcpyDeviceToHost);
@@ -461,6 +461,8 @@ struct Launch {
                 const double w = (double)h[12];
                 fprintf(stderr, "STAMPDB %-70s %-14s waves %6llu items/wave %5.1f | per item: write %6.0f load %6.0f (epi-loads %5.0f index %5.0f bulk %5.0f) mfma %6.0f epi %6.0f barrier %6.0f\n",
                         kname, label, h[15], h[12] / (double)h[15], h[6] / w, h[7] / w, h[0] / w, h[1] / w, h[2] / w, h[8] / w, h[9] / w, h[10] / w);
+                if (strstr(kname, "subpixel"))     // per wave index: the sums are over a quarter of the waves
+                    fprintf(stderr, "STAMPSW %-14s barrier by wave: %6.0f %6.0f %6.0f %6.0f | write wave0 %6.0f wave3 %6.0f\n", label, 4 * h[0] / w, 4 * h[1] / w, 4 * h[2] / w, 4 * h[3] / w, 4 * h[4] / w, 4 * h[5] / w);
             } else if (h[15]) {
                 const double w = (double)h[15];
                 fprintf(stderr, "STAMP %-40s %-16s waves %8llu  load %7.0f  write %6.0f  bar %6.0f  blocks %8.0f  epi %7.0f\n", kname,

@@ -6,8 +6,8 @@
 
 namespace gsa {
 
-// Per-(sample, channel) AdaIN coefficients: out = fmaf(x - mean, A, B)
-// (InstanceNorm + style of reference networks_stylegan.py:250-264, folded).
+// Per-(sample, channel) AdaIN coefficients: out = fmaf(x, A, B), B = fmaf(-mean, A, beta*(ys+1)+yb)
+// (InstanceNorm + style of reference networks_stylegan.py:250-264, folded; `mean` is kept for reference only).
 struct Aff { float mean, A, B, pad; };
 
 // 64-bit fixed-point partial statistics of one (sample, tile-row, channel)

@@ -218,7 +218,7 @@ __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const floa
         float t = f[c];
         if (HAS_AFF) {
             const float4 a = saff[c];    // (mean, A, B, -)
-            t = fmaf(t - a.x, a.y, a.z);
+            t = fmaf(t, a.y, a.z);
         }
         f[c] = inside ? t : 0.0f;
     }
@@ -236,6 +236,22 @@ __device__ __forceinline__ void store_pixel(float* sA, f32x4 (&v)[4], const floa
         dst[1] = f32x4{f[4], f[5], f[6], f[7]};
         dst[2] = f32x4{f[8], f[9], f[10], f[11]};
         dst[3] = f32x4{f[12], f[13], f[14], f[15]};
+    }
+}
+
+// store_pixel with the block's AdaIN coefficients as two structure-of-arrays register sets (A and B of channels 4j..4j+3 in cA[j] /
+// cB[j], read once per ITEM from a [2][16]-float LDS table): one packed fma per two channels and no per-channel table read -- the
+// array-of-structures table of store_pixel costs a 16-byte LDS read and a scalar fma per channel (same values, same bits)
+template <bool MASK>
+__device__ __forceinline__ void store_pixel_soa(float* sA, const f32x4 (&v)[4], const f32x4 (&cA)[4], const f32x4 (&cB)[4], const TilePixel& tp) {
+    const bool inside = !MASK || tp.pix >= 0;
+    if (tp.lds < 0) return;
+    f32x4* dst = reinterpret_cast<f32x4*>(sA + tp.lds);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 t = __builtin_elementwise_fma(v[j], cA[j], cB[j]);
+        dst[j] = inside ? t : z;
     }
 }
 
@@ -270,7 +286,7 @@ __device__ __forceinline__ void store_chunk(float* sA, const f32x4& v, const f32
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         float t = f[c];
-        if (HAS_AFF) t = fmaf(t - aff[c][0], aff[c][1], aff[c][2]);
+        if (HAS_AFF) t = fmaf(t, aff[c][1], aff[c][2]);
         f[c] = inside ? t : 0.0f;
     }
     if (ch.lds < 0) return;
@@ -1123,8 +1139,8 @@ __device__ __forceinline__ void mfma_settle(f32x4 (&a)[16]) {
 // CHUNK = staging by 16-byte chunks with the AdaIN coefficients in registers (see "staging by 16-byte chunks" above): measured
 // faster for the layers with >= 64 input channels (g.64 / g.128 / g.256.conv_2 -4..-9 %), slower for the resident-weight layers
 // with <= 32 (d.main_6.b +11 %, d.cvt_8 +5 %), which therefore keep whole-pixel staging with a two-slot LDS coefficient table.
-template <int EPI, int NT, bool CHUNK>
-__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams p) {
+template <int EPI, int NT, bool CHUNK, bool AFF>      // AFF: the source carries AdaIN coefficients (p.aff0 != null) -- compile time, so that the
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams p) {      // instantiations without it carry none of its code
     constexpr int NTHR = 256, LH = 18, LW = 18, RS = LW * 16 + 4;
     constexpr int SEG = 16 * 256;                // U floats per (16 couts, 16-channel block): 16 frequencies x [ci][16][cg]
     constexpr int NB4 = SEG / 4, BIT = NT * NB4 / NTHR;      // 16-byte pieces of one (16 couts, block) segment; pieces per thread of a block
@@ -1203,7 +1219,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const bool has_aff = p.aff0 != nullptr;
+    constexpr bool has_aff = AFF;
     f32x4 ra[NCH][RW], rb[BIT], raff[4];      // raff: CHUNK: this thread's 4 AdaIN entries; else raff[0] = one entry of the item's 16 (lanes 0-15)
 #pragma unroll
     for (int c = 0; c < 4; ++c) raff[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1230,8 +1246,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         }
     };
     auto write_aff_item = [&](int slot) {        // !CHUNK: the item's 16 entries -> LDS slot (read after the next barrier)
-        if constexpr (!CHUNK) {
-            if (has_aff && tid < 16) sAff[slot * 16 + tid] = raff[0];
+        if constexpr (!CHUNK) {      // structure of arrays: [slot][A of the 16 channels | B of the 16 channels]
+            if (has_aff && tid < 16) {
+                float* tabf = reinterpret_cast<float*>(sAff) + slot * 32;
+                tabf[tid] = raff[0][1]; tabf[16 + tid] = raff[0][2];
+            }
         }
     };
     auto stage_unit = [&](auto aff_tag, auto mask_tag, float* a_img, const float4* tab, int k, const Chunk& u) {
@@ -1242,7 +1261,24 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
     auto write_item = [&](const Chunk (&tp)[NCH], bool edge, int buf) {
         float* a_img = sA + buf * (LH * RS);
         const float4* tab = reinterpret_cast<const float4*>(sAff) + buf * 16;
-        if (has_aff) {
+        bool staged = false;
+        if constexpr (!CHUNK) {
+            if (has_aff) {               // whole pixels: the item's coefficients as packed operands, one table read per item
+                f32x4 cA[4], cB[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cA[j] = sAff[buf * 8 + j]; cB[j] = sAff[buf * 8 + 4 + j]; }
+                if (edge) {
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) store_pixel_soa<true>(a_img, ra[k], cA, cB, TilePixel{tp[k].pix, tp[k].lds});
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) store_pixel_soa<false>(a_img, ra[k], cA, cB, TilePixel{tp[k].pix, tp[k].lds});
+                }
+                staged = true;
+            }
+        }
+        if (staged) {
+        } else if (has_aff) {
             if (edge) {
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) stage_unit(std::true_type{}, std::true_type{}, a_img, tab, k, tp[k]);
@@ -1517,6 +1553,18 @@ __device__ __forceinline__ int wino22_tile_x(int i16) { return ((i16 >> 2) & 1) 
 
 // one 16-channel block: ap = the lane's patch origin in the LDS image (row py / column px of its tile's halo patch, k slot
 // included), bp = the block's weights of this lane ([tap16][kq][16][cg] + (kq*16 + i16)*4), SEG = floats per 16 output channels
+// 2 wait states between the packed adds (inline asm: invisible to the compiler's hazard recognizer) and the MFMAs that read
+// their results; not volatile -- ordered by its operands only (see valu_settle)
+__device__ __forceinline__ void valu_settle8(f32x4& a, f32x4& b, f32x4& c, f32x4& d, f32x4& e, f32x4& f, f32x4& g, f32x4& h) {
+    asm("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+__device__ __forceinline__ void valu_settle5(f32x4& a, f32x4& b, f32x4& c, f32x4& d, f32x4& e) {
+    asm("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+}
+
+#ifndef GSA_W22_PK
+#define GSA_W22_PK 1
+#endif
 template <int NT, int SEG>
 __device__ __forceinline__ void wino22_block(const float* ap, int RS, const float* bp, int py, int px, f32x4 (&acc)[9][NT]) {
     f32x4 V[9];
@@ -1526,11 +1574,19 @@ __device__ __forceinline__ void wino22_block(const float* ap, int RS, const floa
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) d[r][c] = *reinterpret_cast<const f32x4*>(ap + r * RS + c * 16);
-        // rows t0 = d0 - d1, t1 = d1, t2 = d2 - d1; then the same three forms along the columns
+        // rows t0 = d0 - d1, t1 = d1, t2 = d2 - d1; then the same three forms along the columns (packed adds: 24 instructions)
+#if GSA_W22_PK
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { d[0][c] = sub4(d[0][c], d[1][c]); d[2][c] = sub4(d[2][c], d[1][c]); }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { V[3 * r] = sub4(d[r][0], d[r][1]); V[3 * r + 1] = d[r][1]; V[3 * r + 2] = sub4(d[r][2], d[r][1]); }
+        valu_settle8(V[0], V[1], V[2], V[3], V[5], V[6], V[7], V[8]);       // V[4] = d[1][1] comes straight from LDS
+#else
 #pragma unroll
         for (int c = 0; c < 3; ++c) { d[0][c] = d[0][c] - d[1][c]; d[2][c] = d[2][c] - d[1][c]; }
 #pragma unroll
         for (int r = 0; r < 3; ++r) { V[3 * r] = d[r][0] - d[r][1]; V[3 * r + 1] = d[r][1]; V[3 * r + 2] = d[r][2] - d[r][1]; }
+#endif
     }
     // taps of the class filter g[a][b] = Wd[3 - py - 2a][3 - px - 2b]
     const int t00 = ((3 - py) * 4 + (3 - px)) * 256, t01 = ((3 - py) * 4 + (1 - px)) * 256;
@@ -1542,11 +1598,21 @@ __device__ __forceinline__ void wino22_block(const float* ap, int RS, const floa
         U[2] = *reinterpret_cast<const f32x4*>(bp + nt * SEG + t01);
         U[6] = *reinterpret_cast<const f32x4*>(bp + nt * SEG + t10);
         U[8] = *reinterpret_cast<const f32x4*>(bp + nt * SEG + t11);
+#if GSA_W22_PK
+        U[1] = add4(U[0], U[2]);
+        U[7] = add4(U[6], U[8]);
+        U[3] = add4(U[0], U[6]);
+        U[5] = add4(U[2], U[8]);
+        U[4] = add4(U[1], U[7]);
+        valu_settle5(U[1], U[3], U[4], U[5], U[7]);
+#else
         U[1] = U[0] + U[2];
         U[7] = U[6] + U[8];
         U[3] = U[0] + U[6];
         U[5] = U[2] + U[8];
         U[4] = U[1] + U[7];
+        __builtin_amdgcn_sched_barrier(0);      // the whole transform ahead of one MFMA stream (no vector-ALU / MFMA switches inside it)
+#endif
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
@@ -2123,23 +2189,37 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
     load_item(tr, cbr, tpr);
     write_aff_item(1);
     __syncthreads();
+    unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, sw = 0, sl = 0, sm = 0, se = 0, sb = 0;
+    (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)k5; (void)sw; (void)sl; (void)sm; (void)se; (void)sb;
     for (int it = 0; it < iters; ++it) {
+        TICK(k0);
         if (WST && it + 1 < iters) {        // every thread of the workgroup: weight block of iteration it+1 -> the other slot,
             store_w((it + 1) & 1);          // then the block of iteration it+2 -> registers
             load_w((it + 2) % nblk);
         }
         if (it < total_items) {
             if (it + 1 < total_items) write_item(cbr, tpr, is_edge(tr), (it + 1) & 1);
+            TICK(k1);
             Tile t2 = tr; int cb2 = cbr;
             next_item(it + 1, t2, cb2, tpr);
             load_item(t2, cb2, tpr);
+            TICK(k2);
             mfma_item(it & 1, cb, it);
+            TICK(k3);
             if (cb == nitem - 1) epilogue(tc);
             write_aff_item(it & 1);
+            TICK(k4);
             tc = tr; cb = cbr; tr = t2; cbr = cb2;
         }
         __syncthreads();
+        TICK(k5);
+        if (it < total_items) { TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4); TSUM(sb, k4, k5); }
     }
+    TFLUSH(6, sw); TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(9, se); TFLUSH(10, sb);
+    TFLUSH(wave, sb);             // diagnostic: barrier wait by wave index (0-3) ...
+    if (wave == 0) TFLUSH(4, sw); // ... and the write phase of waves 0 and 3
+    if (wave == 3) TFLUSH(5, sw);
+    TFLUSH(12, (unsigned long long)total_items); TFLUSH(15, 1ull);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2432,7 +2512,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p, int row
         Aff a;
         a.mean = mean_f;
         a.A = gsc * s1;
-        a.B = fmaf(p.beta[c], s1, st[p.C + c]);
+        a.B = fmaf(-mean_f, a.A, fmaf(p.beta[c], s1, st[p.C + c]));      // the mean folded into the shift: consumers apply ONE fmaf(x, A, B)
         a.pad = 0.0f;
         p.aff[(size_t)n * p.C + c] = a;
     }
@@ -2707,8 +2787,8 @@ __global__ __launch_bounds__(256) void torgb_direct_kernel(const float* x, const
 #pragma unroll
     for (int c = 0; c < C; c += 4) {
         const f32x4 v = CT > 0 ? pre[c / 4] : act_load4<BF>(x, px + c);
-        const float f[4] = {fmaf(v[0] - a[c].mean, a[c].A, a[c].B), fmaf(v[1] - a[c + 1].mean, a[c + 1].A, a[c + 1].B),
-                            fmaf(v[2] - a[c + 2].mean, a[c + 2].A, a[c + 2].B), fmaf(v[3] - a[c + 3].mean, a[c + 3].A, a[c + 3].B)};
+        const float f[4] = {fmaf(v[0], a[c].A, a[c].B), fmaf(v[1], a[c + 1].A, a[c + 1].B),
+                            fmaf(v[2], a[c + 2].A, a[c + 2].B), fmaf(v[3], a[c + 3].A, a[c + 3].B)};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -2755,8 +2835,8 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* x, const Aff* a
             for (int c = 0; c < cw; c += 4) {
                 const float4 v = *reinterpret_cast<const float4*>(&tile[tid * LS + c]);
                 const Aff* ac = a + c0 + c;
-                const float f[4] = {fmaf(v.x - ac[0].mean, ac[0].A, ac[0].B), fmaf(v.y - ac[1].mean, ac[1].A, ac[1].B),
-                                    fmaf(v.z - ac[2].mean, ac[2].A, ac[2].B), fmaf(v.w - ac[3].mean, ac[3].A, ac[3].B)};
+                const float f[4] = {fmaf(v.x, ac[0].A, ac[0].B), fmaf(v.y, ac[1].A, ac[1].B),
+                                    fmaf(v.z, ac[2].A, ac[2].B), fmaf(v.w, ac[3].A, ac[3].B)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -2791,7 +2871,7 @@ __global__ __launch_bounds__(256) void export_nchw_kernel(const float* x, const 
             if (aff) {
                 const Aff* a = aff + (size_t)n * C + c0 + cq;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) f[j] = fmaf(f[j] - a[j].mean, a[j].A, a[j].B);
+                for (int j = 0; j < 4; ++j) f[j] = fmaf(f[j], a[j].A, a[j].B);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) tile[pl][cq + j] = f[j];
@@ -3222,13 +3302,13 @@ static int wino_nt(const ConvParams& p) {
     return (forced >= 2 && p.Cout % 32 == 0) ? 2 : 1;
 }
 
-template <int EPI, int NT, bool CHUNK>
+template <int EPI, int NT, bool CHUNK, bool AFF>
 static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int RS = 18 * 16 + 4, SEG = 16 * 256;
     const int nblk = p.C0 / 16;
     const bool wres = (size_t)nblk * NT * SEG * sizeof(float) <= (NT == 1 ? 36 : 72) * 1024;      // whole panel of the group resident (<= 32 input channels)
     const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * NT * SEG) + (CHUNK ? 0 : 32 * sizeof(float4));
-    auto kern = conv3x3_wino<EPI, NT, CHUNK>;
+    auto kern = conv3x3_wino<EPI, NT, CHUNK, AFF>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
     int num_cus = 0, wgs_per_cu = 0;
@@ -3246,7 +3326,7 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
             if (e != hipSuccess) return e;
             wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
             if (st.occ_n < 8) { st.occ_lds[st.occ_n] = lds; st.occ_k[st.occ_n] = wgs_per_cu; ++st.occ_n; }
-            if (getenv("GSA_VERBOSE")) fprintf(stderr, "gsa: conv3x3_wino<%d,%d,%d> lds %zu B%s -> %d workgroups/CU\n", EPI, NT, (int)CHUNK, lds, wres ? " (resident weights)" : "", k);
+            if (getenv("GSA_VERBOSE")) fprintf(stderr, "gsa: conv3x3_wino<%d,%d,%d,%d> lds %zu B%s -> %d workgroups/CU\n", EPI, NT, (int)CHUNK, (int)AFF, lds, wres ? " (resident weights)" : "", k);
         }
     }
     ConvParams q = p;
@@ -3285,11 +3365,15 @@ static bool wino_chunk(const ConvParams& p) {
 static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s) {
     const int nt = wino_nt(p);
     const bool ch = wino_chunk(p);
-#define GSA_W(EPI) \
-    if (nt == 2) return ch ? launch_wino_t<EPI, 2, true>(p, n, s) : launch_wino_t<EPI, 2, false>(p, n, s); \
-    return ch ? launch_wino_t<EPI, 1, true>(p, n, s) : launch_wino_t<EPI, 1, false>(p, n, s);
-    if (epi == EPI_SYNTH) { GSA_W(EPI_SYNTH) }
-    GSA_W(EPI_DEC)
+#define GSA_W(EPI, AFF) \
+    if (nt == 2) return ch ? launch_wino_t<EPI, 2, true, AFF>(p, n, s) : launch_wino_t<EPI, 2, false, AFF>(p, n, s); \
+    return ch ? launch_wino_t<EPI, 1, true, AFF>(p, n, s) : launch_wino_t<EPI, 1, false, AFF>(p, n, s);
+    if (epi == EPI_SYNTH) {
+        if (p.aff0) { GSA_W(EPI_SYNTH, true) }
+        GSA_W(EPI_SYNTH, false)
+    }
+    if (p.aff0) { GSA_W(EPI_DEC, true) }
+    GSA_W(EPI_DEC, false)
 #undef GSA_W
 }
 
@@ -3297,7 +3381,7 @@ static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s
 const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     static thread_local char buf[128];
     if (conv_uses_wino(p, epi, sc)) {
-        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d, %d, %s>(gsa::ConvParams)", epi, wino_nt(p), wino_chunk(p) ? "true" : "false");
+        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d, %d, %s, %s>(gsa::ConvParams)", epi, wino_nt(p), wino_chunk(p) ? "true" : "false", p.aff0 ? "true" : "false");
         return buf;
     }
     if (conv_uses_ksplit(p, sc)) {
@@ -3433,7 +3517,8 @@ static size_t subpixel_res_lds(const ConvParams& p, int ct, bool sc, int n) {
     const size_t fixed = sizeof(float) * ((size_t)nblk * nt * 16 * ts + (sc ? (size_t)nblk * nt * ts : 0));
     const long tiles = (long)(p.H / 16) * (p.W / 16) * n;
     if (tiles < 4096) return 0;
-    for (int kb = (nblk % 2 == 0 && nblk >= 4) ? 2 : 1; kb >= 1; --kb) {     // two blocks per item pay off from 4 blocks on
+    const int kb_min_blocks = sub_wino(p) ? 2 : 4;      // Winograd form: 36 MFMAs per block instead of 64 -- a two-block tile is one item
+    for (int kb = (nblk % 2 == 0 && nblk >= kb_min_blocks) ? 2 : 1; kb >= 1; --kb) {     // two blocks per item pay off from 4 blocks on
         const size_t lds = fixed + sizeof(float) * 4 * kb * 10 * rs + 64 * kb * sizeof(float4);
         if (lds <= 160 * 1024) return lds;
     }
@@ -3445,7 +3530,7 @@ static int subpixel_res_kb(const ConvParams& p) {
     const int nblk = (p.C0 + p.C1) / 16, nt = p.Cout / 16;
     const bool sc = p.wsc != nullptr;
     const size_t fixed = sizeof(float) * ((size_t)nblk * nt * 16 * ts + (sc ? (size_t)nblk * nt * ts : 0));
-    if (nblk % 2 || nblk < 4) return 1;
+    if (nblk % 2 || nblk < (sub_wino(p) ? 2 : 4)) return 1;
     return fixed + sizeof(float) * 4 * 2 * 10 * rs + 128 * sizeof(float4) <= 160 * 1024 ? 2 : 1;
 }
 

@@ -523,7 +523,8 @@ static void plane_stats(const float* x, int H, int W, int C, uint64_t* I1, uint6
 }
 
 /* InstanceNorm(eps 1e-5, biased variance) folded with the AdaIN style (reference
- * networks_stylegan.py:250-264):  out = IN(x)*(ys+1)+yb = fmaf(x-mean, A, B) */
+ * networks_stylegan.py:250-264):  out = IN(x)*(ys+1)+yb = fmaf(x, A, B) with the mean folded into the shift,
+ * B = fmaf(-mean, A, beta*(ys+1)+yb) (round 3: one operation per element for every consumer instead of two) */
 static void finalize(const uint64_t* I1, const uint64_t* I2, int HW, int C, const float* style /*2C*/,
                      const float* gamma, const float* beta, affine3* out) {
     const double inv_hw = 1.0 / (double)HW; /* HW is a power of two: exact */
@@ -538,14 +539,14 @@ static void finalize(const uint64_t* I1, const uint64_t* I2, int HW, int C, cons
         float s1 = style[c] + 1.0f;
         out[c].mean = mean_f;
         out[c].A = g * s1;
-        out[c].B = fmaf(beta[c], s1, style[C + c]);
+        out[c].B = fmaf(-mean_f, out[c].A, fmaf(beta[c], s1, style[C + c]));
     }
 }
 
 static void apply_affine(const float* x, size_t npix, int C, const affine3* a, float* out) {
 #pragma omp parallel for schedule(static)
     for (size_t p = 0; p < npix; ++p)
-        for (int c = 0; c < C; ++c) out[p * C + c] = fmaf(x[p * C + c] - a[c].mean, a[c].A, a[c].B);
+        for (int c = 0; c < C; ++c) out[p * C + c] = fmaf(x[p * C + c], a[c].A, a[c].B);
 }
 
 /* y[j] = (chain_k fmaf(x[k], W[j][k], 0)) + b[j] */
