@@ -19,7 +19,7 @@ API_SYMBOLS = (
     "generator_commit", "decoder_init", "decoder_set_param", "decoder_commit", "reserve",
     "generator_forward", "decoder_forward", "generate", "set_overlap", "set_precision", "segmentation_eval", "fill_inputs",
     "profile_enable", "profile_collect",
-    "profile_entry", "profile_reset", "version",
+    "profile_entry", "profile_reset", "version", "check",
 )
 
 
@@ -84,6 +84,7 @@ class Api:
                                         c.POINTER(c.c_double), c.POINTER(c.c_double)]),
             "profile_reset": (c.c_int, [vp]),
             "version": (c.c_char_p, []),
+            "check": (c.c_int, [vp]),
         }
         for name, (res, args) in sig.items():
             try:
@@ -128,6 +129,7 @@ class Context:
         self.generator_cfg = None
         self.decoder_cfg = None
         self.precision = "fp32"
+        self._checked_first_step = False
 
     def _msg(self, h):
         m = self.api.last_error(h)
@@ -138,10 +140,26 @@ class Context:
             raise GsaError("%s failed (%d): %s" % (what, rc, self._msg(self._h)))
         return rc
 
+    def check(self):
+        """gsa_check: synchronise the device and raise GsaError if a device-side check failed since the last clean one (the
+        fused mapping network's exchange timed out; an instance-norm statistic left its fixed-point range)."""
+        self._check(self.api.check(self._h), "check")
+
+    def _after_step(self):
+        # ONE synchronising check per context, after its first step: a violated co-residency assumption or out-of-range
+        # activations would otherwise yield wrong pairs with a zero status (the calls are stream-ordered); close() checks again
+        if not self._checked_first_step:
+            self._checked_first_step = True
+            self.check()
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            self.api.destroy(self._h)
-            self._h = ctypes.c_void_p()
+            try:
+                if self._checked_first_step:
+                    self.check()
+            finally:
+                self.api.destroy(self._h)
+                self._h = ctypes.c_void_p()
 
     def __del__(self):
         try:
@@ -197,6 +215,7 @@ class Context:
         fp = _ptr_array(feats) if feats is not None else None
         self._check(self.api.generator_forward(self._h, stream, n, z, _ptr_array(noise), len(noise), rgb, img, fp,
                                                len(feats) if feats is not None else 0), "generator_forward")
+        self._after_step()
 
     def decoder_forward(self, stream, n, feats, logits=None, mask=None):
         self._check(self.api.decoder_forward(self._h, stream, n, _ptr_array(feats), len(feats), logits, mask),
@@ -204,6 +223,7 @@ class Context:
 
     def generate(self, stream, n, z, noise, img, mask):
         self._check(self.api.generate(self._h, stream, n, z, _ptr_array(noise), len(noise), img, mask), "generate")
+        self._after_step()
 
     def set_precision(self, precision):
         """"fp32" (default, bit-exact canonical path) or "bf16" (bf16 MFMA operands); before the weights are loaded."""

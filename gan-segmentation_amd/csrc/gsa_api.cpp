@@ -124,6 +124,10 @@ struct gsa_ctx {
     int prio = 0;                 // GSA_PRIO experiment switch
     int dbg = 0;                  // GSA_DBG, read once at gsa_create (only the diagnostic build looks at it)
     int side_levels = -1;         // decoder levels 0..side_levels-1 go to the side stream; -1 = by batch size (GSA_SIDE_LEVELS)
+    int fault = 0;                // GSA_FAULT (tests only), read at gsa_create: 1 = the fused mapping network is launched one workgroup short;
+                                  // 2 = the first generator pass returns an error between a statistics producer and its finalize
+    size_t partials_bytes = 0, stat_acc_bytes = 0, ticket_bytes = 0;
+    bool stats_dirty = false;     // a generator pass failed between a statistics producer and its finalize: the rows are re-zeroed by the next pass
 
     // profiling
     int prof = 0;
@@ -484,7 +488,14 @@ const char* conv_kernel_name(const ConvParams& cp, int n, int epi, bool sc) { re
 
 extern "C" {
 
-const char* gsa_version(void) { return "gsa-hip 0.1 (gfx950, v_mfma_f32_16x16x4_f32 implicit-GEMM convs)"; }
+// the compiler is part of the build string: the s_nop padding around the inline-asm packed adds (valu_settle / mfma_settle,
+// gsa_kernels.hip) is correct for the instruction order THIS hipcc emits; the bit-exact parity tests are what re-validates it
+#define GSA_STR2(x) #x
+#define GSA_STR(x) GSA_STR2(x)
+const char* gsa_version(void) {
+    return "gsa-hip 0.3 (gfx950, v_mfma_f32_16x16x4_f32 implicit-GEMM convs; built with hipcc = clang " __clang_version__
+           ", HIP " GSA_STR(HIP_VERSION_MAJOR) "." GSA_STR(HIP_VERSION_MINOR) "." GSA_STR(HIP_VERSION_PATCH) ")";
+}
 
 int gsa_create(int device, gsa_ctx** out) {
     if (!out) return fail(nullptr, GSA_ERR_INVALID, "gsa_create: out is null");
@@ -509,6 +520,7 @@ int gsa_create(int device, gsa_ctx** out) {
     if (const char* v = getenv("GSA_SIDE_LEVELS")) c->side_levels = atoi(v);
     if (const char* v = getenv("GSA_DBG")) c->dbg = atoi(v);
     if (const char* v = getenv("GSA_PRIO")) c->prio = atoi(v);
+    if (const char* v = getenv("GSA_FAULT")) c->fault = atoi(v);
     *out = c;
     return GSA_OK;
 }
@@ -819,12 +831,34 @@ int gsa_decoder_commit(gsa_ctx* c) {
 
 // ------------------------------------------------------------------------ workspace
 
+// Reads and clears the sticky device words (map_ctl[0]: instance-norm statistics out of range, map_ctl[1]: the mapping
+// network's exchange timed out).  The device must be idle (the callers synchronise first).
+static int read_device_status(gsa_ctx* c) {
+    if (!c->map_ctl) return GSA_OK;
+    unsigned w[2] = {0u, 0u};
+    HIP_TRY(hipMemcpy(w, c->map_ctl, sizeof w, hipMemcpyDeviceToHost));
+    if (!w[0] && !w[1]) return GSA_OK;
+    HIP_TRY(hipMemset(c->map_ctl, 0, sizeof w));
+    return fail(c, GSA_ERR_DEVICE, "device-side check failed since the last clean check:%s%s -- discard the results of those steps",
+                w[1] ? " the fused mapping network timed out waiting for a partner workgroup (its workgroups were not co-resident)" : "",
+                w[0] ? " an instance-norm statistic left the range of its 64-bit fixed-point sum (activations beyond rms ~1.4e3 at 1024^2; include/gsa.h)" : "");
+}
+
+int gsa_check(gsa_ctx* c) {
+    if (!c) return GSA_ERR_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return read_device_status(c);
+}
+
 int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
     if (!c) return GSA_ERR_INVALID;
     if (max_batch < 1) return fail(c, GSA_ERR_INVALID, "max_batch must be >= 1");
     if (!c->g_ready && !c->d_ready) return fail(c, GSA_ERR_STATE, "commit a generator or decoder before gsa_reserve");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
+    if (int rc = read_device_status(c)) return rc;      // a condition recorded by earlier steps is reported before its words are freed
+    c->map_ctl = nullptr;
     free_all(c->ws_allocs);
     c->max_batch = 0;
     const size_t N = (size_t)max_batch;
@@ -858,6 +892,10 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
         if (int rc = dev_alloc(c, N * maxC, &c->aff1, T)) return rc;
         prow_elems = std::max(prow_elems, (size_t)64 * maxC);
         if (int rc = dev_alloc(c, N * prow_elems, &c->partials, T)) return rc;
+        c->partials_bytes = N * prow_elems * sizeof(StatPart);
+        c->stat_acc_bytes = N * maxC * sizeof(StatPart);
+        c->ticket_bytes = N * ((maxC + 63) / 64) * sizeof(unsigned);
+        c->stats_dirty = false;
         HIP_TRY(hipMemset(c->partials, 0, N * prow_elems * sizeof(StatPart)));     // all zero between layers: finalize_kernel clears what it read
         if (int rc = dev_alloc(c, N * maxC, &c->stat_acc, T)) return rc;
         HIP_TRY(hipMemset(c->stat_acc, 0, N * maxC * sizeof(StatPart)));
@@ -888,15 +926,35 @@ int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
 
 // ------------------------------------------------------------------------ forward passes
 
+static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, const float* const* noise, float* rgb,
+                              uint8_t* img, float* const* feats, bool record_levels);
+
+// The statistics rely on `partials` / `stat_acc` / the tickets being all zero between layers (the producers ADD to their rows,
+// finalize_kernel clears what it read).  A pass that fails between a producer and its finalize (a launch error, a null noise
+// plane) would leave rows dirty and every later pass of the context would add them into its instance-norm sums: the context
+// remembers that a pass did not complete and the next one re-zeroes the three buffers on its stream first.
 static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const float* const* noise, float* rgb,
                          uint8_t* img, float* const* feats, bool record_levels = false) {
+    if (c->stats_dirty) {
+        HIP_TRY(hipMemsetAsync(c->partials, 0, c->partials_bytes, s));
+        HIP_TRY(hipMemsetAsync(c->stat_acc, 0, c->stat_acc_bytes, s));
+        HIP_TRY(hipMemsetAsync(c->stat_tickets, 0, c->ticket_bytes, s));
+    }
+    c->stats_dirty = true;
+    const int rc = run_generator_pass(c, s, n, z, noise, rgb, img, feats, record_levels);
+    if (rc == GSA_OK) c->stats_dirty = false;
+    return rc;
+}
+
+static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, const float* const* noise, float* rgb,
+                              uint8_t* img, float* const* feats, bool record_levels) {
     const int L = c->gc.latent_size, nlev = c->nlev;
     const double N = n;
     // mapping network: PixelNorm, 8 x (dense + LeakyReLU)
     int cur = 0;
     if (mapping_fused(L, c->device)) {
         Launch lp(c, s, "mapping_kernel", "g.mapping", 3.0 * N * L + 16.0 * N * L * L, 4.0 * (8.0 * L * (double)L + 18 * N * L));
-        HIP_TRY(launch_mapping(z, c->map_wt, c->map_b, c->map_ll, c->lat[0], c->map_ctl, n, L, c->device, s));
+        HIP_TRY(launch_mapping(z, c->map_wt, c->map_b, c->map_ll, c->lat[0], c->map_ctl, n, L, c->device, s, c->fault == 1 ? 1 : 0));
     } else {
         { Launch lp(c, s, "pixelnorm_kernel", "g.mapping.pixelnorm", 3.0 * N * L, 8.0 * N * L);
           HIP_TRY(launch_pixelnorm(z, c->lat[0], n, L, s)); }
@@ -964,11 +1022,16 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
                 prow = rows;
             }
+            if (c->fault == 2 && l == 1 && k == 1) {      // fault injection (tests): ONE pass dies between a producer and its finalize
+                c->fault = 0;
+                return fail(c, GSA_ERR_HIP, "injected fault (GSA_FAULT=2) between a statistics producer and its finalize");
+            }
             FinalizeParams fp{};
             fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C; fp.acc = c->stat_acc; fp.tickets = c->stat_tickets;
             fp.style = c->styles + B.style_off[k]; fp.style_stride = c->style_cols;
             fp.gamma = B.gamma[k]; fp.beta = B.beta[k];
             fp.aff = k == 0 ? c->aff1 : c->aff2[l];
+            fp.flags = c->map_ctl;      // word 0: statistics range check
             snprintf(layer, sizeof layer, "g.%d.finalize_%d", R, k + 1);
             Launch lp(c, s, "finalize_kernel", layer, 0.0, 16.0 * N * prow * C);
             HIP_TRY(launch_finalize(fp, n, s));
@@ -1200,6 +1263,8 @@ int gsa_profile_collect(gsa_ctx* c) {
         c->event_pool.push_back(ev.b);
     }
     c->prof_events.clear();
+    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = read_device_status(c)) return rc;
     return (int)c->prof_entries.size();
 }
 

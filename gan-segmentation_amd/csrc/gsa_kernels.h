@@ -67,6 +67,7 @@ struct FinalizeParams {
     const float* style; int style_stride;  // style[n*style_stride + c] = ys, [.. + C + c] = yb
     const float* gamma; const float* beta;
     Aff* aff;   // [n][C]
+    unsigned* flags;   // sticky device word or null: set to 1 when a sum is within a factor 4 of its 64-bit wrap or the variance is negative
 };
 
 // launches (all stream-ordered, no sync)
@@ -83,7 +84,7 @@ hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_
 constexpr int kMapSlices = 8;     // most sample slices of the fused mapping network (launch-number words ctl[2 .. 2 + kMapSlices))
 bool mapping_fused(int L, int device);
 hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, unsigned long long* const* ll, float* out, unsigned* ctl,
-                          int n, int L, int device, hipStream_t s);
+                          int n, int L, int device, hipStream_t s, int drop_workgroups = 0);   // drop_workgroups: fault injection (tests)
 hipError_t launch_dense(const float* x, const float* WT, const float* b, float* y, int n, int K, int J,
                         int lrelu, hipStream_t s);
 hipError_t launch_styles(const float* w, const float* avg, const float* psi, const float* WT, const float* b,

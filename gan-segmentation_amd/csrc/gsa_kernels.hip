@@ -39,6 +39,9 @@
 #endif
 // double-buffered (prefetch two items ahead, one barrier per item) form also for the 8x8 / 4x4 tiles of the 4^2-16^2 layers:
 // their 32 channel blocks were 32 dependent load -> LDS -> barrier rounds with ONE block in flight per workgroup
+#ifndef GSA_WINO_SOA
+#define GSA_WINO_SOA 0
+#endif
 #ifndef GSA_DB_SMALL
 #define GSA_DB_SMALL 1
 #endif
@@ -1220,6 +1223,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         for (int nt = 0; nt < NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr bool has_aff = AFF;
+    // whole-pixel staging with the coefficients as structure-of-arrays registers (8 packed fma per pixel instead of 16 table reads +
+    // 16 scalar fma, store_pixel_soa): measured 3 % SLOWER on the four layers that use it (d.cvt_7/8 0.265/0.292 -> 0.273/0.306 ms,
+    // g.512/g.1024.conv_2 0.277/0.333 -> 0.287/0.337): packed fp32 operations cost more issue time beside the MFMA stream than
+    // the scalar pair.  Kept for A/B builds (-DGSA_WINO_SOA=1); same bits.
+    constexpr bool kSoA = GSA_WINO_SOA != 0;
     f32x4 ra[NCH][RW], rb[BIT], raff[4];      // raff: CHUNK: this thread's 4 AdaIN entries; else raff[0] = one entry of the item's 16 (lanes 0-15)
 #pragma unroll
     for (int c = 0; c < 4; ++c) raff[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1246,11 +1254,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         }
     };
     auto write_aff_item = [&](int slot) {        // !CHUNK: the item's 16 entries -> LDS slot (read after the next barrier)
-        if constexpr (!CHUNK) {      // structure of arrays: [slot][A of the 16 channels | B of the 16 channels]
+        if constexpr (!CHUNK && kSoA) {      // structure of arrays: [slot][A of the 16 channels | B of the 16 channels]
             if (has_aff && tid < 16) {
                 float* tabf = reinterpret_cast<float*>(sAff) + slot * 32;
                 tabf[tid] = raff[0][1]; tabf[16 + tid] = raff[0][2];
             }
+        } else if constexpr (!CHUNK) {
+            if (has_aff && tid < 16) sAff[slot * 16 + tid] = raff[0];
         }
     };
     auto stage_unit = [&](auto aff_tag, auto mask_tag, float* a_img, const float4* tab, int k, const Chunk& u) {
@@ -1262,7 +1272,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         float* a_img = sA + buf * (LH * RS);
         const float4* tab = reinterpret_cast<const float4*>(sAff) + buf * 16;
         bool staged = false;
-        if constexpr (!CHUNK) {
+        if constexpr (!CHUNK && kSoA) {
             if (has_aff) {               // whole pixels: the item's coefficients as packed operands, one table read per item
                 f32x4 cA[4], cB[4];
 #pragma unroll
@@ -2503,6 +2513,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p, int row
         const double m = (double)(long long)I1 * (1.0 / kStatScale1) * inv_hw;
         const double e2 = (double)(long long)I2 * (1.0 / kStatScale2) * inv_hw;
         double var = fma(-m, m, e2);
+        // range check of the fixed-point sums (include/gsa.h): a sum within a factor 4 of the 64-bit wrap, or a variance that is
+        // negative beyond rounding (what a wrapped sum of squares produces), sets the sticky word gsa_check reports
+        {
+            const long long s1 = (long long)I1;
+            const bool near_wrap = (s1 < 0 ? -s1 : s1) >= (1ll << 61) || I2 >= (1ull << 61);
+            if (p.flags && (near_wrap || var < -1e-6 * (e2 + m * m) - 1e-30)) atomicOr(p.flags, 1u);
+        }
         if (!(var > 0.0)) var = 0.0;
         const float mean_f = (float)m, var_f = (float)var;
         const float inv = 1.0f / sqrtf(var_f + 1e-5f);
@@ -2640,7 +2657,8 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const float* x, const fl
 // suffice: a workgroup can only be two layers ahead of another one after that one has consumed the older buffer.
 // Arithmetic per output is unchanged: the canonical k-ordered fmaf chains of pixelnorm_kernel / dense_lds_kernel.
 // All L/16 workgroups must be resident together (the launcher keeps the grid within half the CU count); a wait gives up
-// after ~0.2 s instead of spinning forever if that is ever violated (the error word is set, the results are garbage).
+// after 0.25 s of wall time instead of spinning forever if that is ever violated: the sticky error word ctl[1] is set, the
+// results of the step are garbage, and the host reports it at its next synchronisation point (gsa_check, include/gsa.h).
 struct MappingParams {
     const float* z;                  // [n][L]
     const float* wt[8];              // [K = L][J = L]
@@ -2691,6 +2709,7 @@ __global__ __launch_bounds__(256) void mapping_kernel(MappingParams p) {
         for (int i = 0; i < 32; ++i)
             if (tid + i * 256 < cnt) pending |= 1u << i;
         int spins = 0;
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         while (pending) {
             unsigned long long v[32];
 #pragma unroll
@@ -2704,7 +2723,12 @@ __global__ __launch_bounds__(256) void mapping_kernel(MappingParams p) {
                 }
             if (pending) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 20)) { atomicExch(p.ctl + 1, 1u); break; }      // never expected: see the header (ctl[1] = error word)
+                // never expected (see the header).  Bounded by ELAPSED TIME: s_memrealtime ticks at 100 MHz -- 0.25 s; a partner
+                // that already gave up (ctl[1] set) ends the wait at once.  ctl[1] is the sticky error word gsa_check reports.
+                if ((++spins & 255) == 0) {
+                    const bool late = __builtin_amdgcn_s_memrealtime() - t_start > 25000000ull;
+                    if (late || __hip_atomic_load(p.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { atomicExch(p.ctl + 1, 1u); break; }
+                }
             }
         }
     };
@@ -3696,7 +3720,7 @@ bool mapping_fused(int L, int device) {
 }
 
 hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, unsigned long long* const* ll, float* out, unsigned* ctl,
-                          int n, int L, int device, hipStream_t s) {
+                          int n, int L, int device, hipStream_t s, int drop_workgroups) {
     if (!mapping_fused(L, device)) return hipErrorInvalidValue;
     MappingParams p;
     p.z = z;
@@ -3719,7 +3743,9 @@ hipError_t launch_mapping(const float* z, float* const* wt, float* const* b, uns
         num_cus = device_cus(device);
     }
     const int slices = std::max(1, std::min(std::min((n + 15) / 16, kMapSlices), (num_cus / 2) / (L / 16)));
-    hipLaunchKernelGGL(kern, dim3(L / 16, slices), dim3(256), lds, s, p);
+    // drop_workgroups > 0 (fault injection, tests only): the last workgroups are not launched, their columns never arrive and
+    // every other workgroup's wait times out -- the condition gsa_check must report
+    hipLaunchKernelGGL(kern, dim3(std::max(1, L / 16 - drop_workgroups), slices), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 

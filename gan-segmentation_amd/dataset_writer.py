@@ -278,7 +278,9 @@ class DatasetWriter:
         t0 = time.perf_counter()
         while True:
             with self._lock:
-                done = self.written + len(self._errors) >= self.submitted
+                # any recorded error ends the wait at once: one batch-level failure stands for N pairs that will never be
+                # counted, so "written + errors >= submitted" alone would spin until the timeout and hide the real exception
+                done = bool(self._errors) or self.written >= self.submitted
             if done:
                 break
             if time.perf_counter() - t0 > timeout:

@@ -117,10 +117,13 @@ class SegSolver:
         import torch.distributed as tdist
         world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
         rank = tdist.get_rank() if world > 1 else 0
+        if world > 1 and len(names) < world:
+            # every rank would train on the full list while all-reducing gradients: the same samples `world` times per step
+            raise ValueError("data-parallel fit: %d training samples for %d ranks -- use at most one rank per sample" % (len(names), world))
         for epoch in range(epochs):
             order = list(names)
             rng.shuffle(order)           # the same permutation on every rank (same seed) ...
-            if world > 1 and len(order) >= world:   # ... of which rank r takes every world-th sample: the trainer
+            if world > 1:                           # ... of which rank r takes every world-th sample: the trainer
                 order = order[:len(order) - len(order) % world][rank::world]   # all-reduces the gradients, so a step sees `world` samples
             total = 0.0
             for fname in order:
@@ -137,6 +140,8 @@ class SegSolver:
         self.load_parameters(tr.state_dict())
         if rank == 0:
             self.save()
+        if world > 1:
+            tdist.barrier()      # no rank may go on to load() the checkpoint rank 0 is still writing
         return history
 
     # -- evaluation ------------------------------------------------------

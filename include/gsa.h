@@ -17,7 +17,8 @@
  *  - one context per (device, host thread); contexts are not thread-safe;
  *  - instance-norm statistics are order-independent 64-bit fixed-point sums (2^-28 for sums, 2^-20 for squares, per aligned
  *    quad of 4 pixels): exact and deterministic while |x| < 2.3e4 per value and rms(x) < 2.9e3 over a 1024^2 plane (mean |x| <
- *    3.2e4); beyond that the sums wrap silently.  Post-LeakyReLU StyleGAN-v1 activations are O(1..100);
+ *    3.2e4); beyond that the sums wrap.  A sum within a factor 4 of the wrap (or a variance that comes out negative) sets a
+ *    sticky device word that gsa_check reports as GSA_ERR_DEVICE.  Post-LeakyReLU StyleGAN-v1 activations are O(1..100);
  *  - tensors crossing the boundary use the reference's layouts: fp32 NCHW activations,
  *    OIHW conv weights, (N,H,W,3) u8 RGB images, (N,H,W) u8 masks.
  *
@@ -41,7 +42,8 @@ typedef enum {
     GSA_ERR_STATE = -2,        /* call order (e.g. forward before commit) */
     GSA_ERR_MISSING_PARAM = -3,/* a declared parameter was never set (reference: load_parameters without allow_missing) */
     GSA_ERR_HIP = -4,          /* HIP runtime error; see gsa_last_error */
-    GSA_ERR_NOMEM = -5
+    GSA_ERR_NOMEM = -5,
+    GSA_ERR_DEVICE = -6        /* a device-side check failed (reported by gsa_check: see there) */
 } gsa_status;
 
 /* Generator(config): reference networks_stylegan.py:78-91 (+ image_generator.py:46-74). */
@@ -169,6 +171,19 @@ int gsa_fill_inputs(gsa_ctx* ctx, void* stream, int32_t n, uint64_t seed, uint64
 int gsa_segmentation_eval(gsa_ctx* ctx, void* stream, int32_t n, int32_t classes, int32_t H, int32_t W,
                           const float* logits, const int8_t* labels, uint64_t* confusion, uint64_t* loss_fixed);
 
+/* Device-side checks.  The forward calls are stream-ordered and return before their kernels ran, so two conditions that a
+ * kernel can only detect on the device are recorded in sticky device words and reported HERE:
+ *   - the fused mapping network (PixelNorm + 8 DenseW in one launch, reference networks_stylegan.py:128-139) exchanges
+ *     activations between its workgroups; if a workgroup waited longer than ~0.25 s for a partner (the launch's workgroups
+ *     were not co-resident: CU masking, a long kernel of another stream holding the chip) the latents of that step are invalid;
+ *   - an instance-norm statistic (networks_stylegan.py:246,261) came within a factor 4 of the 64-bit wrap of its fixed-point
+ *     sum, or produced a negative variance: activations beyond the range stated above.
+ * gsa_check synchronises the device, returns GSA_OK or GSA_ERR_DEVICE (gsa_last_error names the condition) and clears the
+ * words.  The Python shim calls it after a context's first step and when a context is closed; gsa_reserve and
+ * gsa_profile_collect (which synchronise anyway) report the same condition.  Results produced since the previous clean check
+ * must be discarded when it fails. */
+int gsa_check(gsa_ctx* ctx);
+
 /* --- measurement hooks (bench.py) ------------------------------------------------------ */
 
 /* When enabled every kernel launch is bracketed by hipEvents on the launch stream. */
@@ -183,7 +198,8 @@ int gsa_profile_entry(gsa_ctx* ctx, int32_t i, const char** name, double* ms, in
                       double* flops, double* bytes, double* alg_flops);
 int gsa_profile_reset(gsa_ctx* ctx);
 
-/* Library build string (version, arch). */
+/* Library build string: version, arch, and the compiler it was built with (the hand-placed s_nop hazard padding around the
+ * inline-asm packed adds of the Winograd kernels was validated on exactly that compiler: DESIGN.md section 4). */
 const char* gsa_version(void);
 
 #ifdef __cplusplus

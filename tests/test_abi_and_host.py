@@ -192,6 +192,28 @@ def test_dataset_writer_files_and_throughput(tmp_path):
     assert j.shape == (R, R, 3) and np.abs(j.astype(int) - img[3].astype(int)).mean() < 3
 
 
+
+def test_dataset_writer_drain_surfaces_a_batch_level_error(tmp_path):
+    """ONE batch-level failure stands for N pairs that are never counted: drain() must raise that exception at once instead
+    of spinning until its timeout (bench.py's to-disk measurement would hang for ten minutes)."""
+    import time
+    from gan_segmentation_amd.dataset_writer import DatasetWriter
+    img = np.zeros((4, 16, 16, 3), np.uint8)
+    mask = np.zeros((4, 16, 16), np.uint8)
+    w = DatasetWriter(str(tmp_path), workers=2)
+
+    def boom(*a, **k):
+        raise RuntimeError("the pool is gone")
+    w.pool.submit = boom
+    w.submit(img, mask, 0)
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="the pool is gone"):
+        w.drain(timeout=60.0)
+    assert time.perf_counter() - t0 < 10.0
+    with pytest.raises(RuntimeError, match="the pool is gone"):
+        w.close()
+
+
 def test_mask_png_bytes_decodes_back():
     """The writer's own PNG container (zlib level 1, run-length strategy): lossless, 8-bit greyscale, valid CRCs."""
     import io

@@ -529,6 +529,56 @@ def test_large_activations_stay_bit_exact(torch_cuda, oracle_lib):
     assert_same(mask.cpu().numpy(), mask_o, "mask")
 
 
+
+def test_device_side_checks_are_reported(torch_cuda, oracle_lib, monkeypatch):
+    """The silent-failure holes of the stream-ordered path (include/gsa.h gsa_check), each with a forced condition:
+    (a) the fused mapping network's exchange times out (one workgroup short: GSA_FAULT=1 at gsa_create) -> GSA_ERR_DEVICE;
+    (b) an instance-norm statistic leaves its fixed-point range (one level's weights scaled by 1e4) -> GSA_ERR_DEVICE;
+    (c) a pass that fails half way (an injected error between a statistics producer and its finalize: GSA_FAULT=2; a null
+        noise plane at level 3) leaves no dirty statistic rows behind: the next pass on the same context is still bit-exact."""
+    from gan_segmentation_amd._lib import GsaError
+    gcfg, gp, dcfg, dp, z, noise = reduced_setup(7, batch=2, trivial_norm=False)
+    img_o, mask_o = oracle_lib.Oracle(gcfg, gp, dcfg, dp).generate(z, noise)
+    # (a)
+    monkeypatch.setenv("GSA_FAULT", "1")
+    bad = _build(gcfg, gp, dcfg, dp, 2)
+    monkeypatch.delenv("GSA_FAULT")
+    with pytest.raises(GsaError, match="mapping network timed out"):
+        bad.generate_batch(z, noise)                 # the shim checks after a context's first step
+    bad.netG._model.ctx.check()                      # reported once, then clear again
+    del bad
+    # (b)
+    gp_big = dict(gp)
+    gp_big["128_conv_2_weight"] = (np.asarray(gp["128_conv_2_weight"], np.float32) * np.float32(1e4)).astype(np.float32)
+    big = _build(gcfg, gp_big, dcfg, dp, 2)
+    with pytest.raises(GsaError, match="instance-norm statistic"):
+        big.generate_batch(z, noise)
+    del big
+    # (c) first an injected failure between a producer and its finalize (dirty rows), then an argument error half way
+    monkeypatch.setenv("GSA_FAULT", "2")
+    gen = _build(gcfg, gp, dcfg, dp, 2)
+    monkeypatch.delenv("GSA_FAULT")
+    with pytest.raises(GsaError, match="injected fault"):
+        gen.generate_batch(z, noise)
+    img, mask = gen.generate_batch(z, noise)
+    assert_same(img.cpu().numpy(), img_o, "image after the injected fault")
+    assert_same(mask.cpu().numpy(), mask_o, "mask after the injected fault")
+    holes = [torch_cuda.from_numpy(a).cuda() for a in noise]
+    zd = torch_cuda.from_numpy(z).cuda()
+    ctx = gen.netG._model.ctx
+    img_t = torch_cuda.empty((2, 128, 128, 3), dtype=torch_cuda.uint8, device="cuda")
+    mask_t = torch_cuda.empty((2, 128, 128), dtype=torch_cuda.uint8, device="cuda")
+    ptrs = [a.data_ptr() for a in holes]
+    ptrs[6] = None                                    # level 3, first plane: the levels before it have launched
+    with pytest.raises(GsaError, match="noise plane 6 is null"):
+        ctx.generate(torch_cuda.cuda.current_stream().cuda_stream, 2, zd.data_ptr(), ptrs, img_t.data_ptr(), mask_t.data_ptr())
+    img2, mask2 = gen.generate_batch(z, noise)
+    assert_same(img2.cpu().numpy(), img_o, "image after the failing call")
+    assert_same(mask2.cpu().numpy(), mask_o, "mask after the failing call")
+    ctx.check()
+    assert "hipcc" in ctx.api.version().decode() and "clang" in ctx.api.version().decode()
+
+
 _SWITCH_WORKER = r'''
 import sys
 sys.path.insert(0, ROOT_DIR)
