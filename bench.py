@@ -369,7 +369,11 @@ def main():
             ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9 if top["ms"] > 0 else 0.0
         roofline = {"bound": bound, "kernel": top["name"], "achieved": round(ach, 3), "peak": peak,
                     "unit": unit, "frac": round(ach / peak, 4),
+                    # what the pipes really do (read these first): the FLOP the matrix cores issue (Winograd / sub-pixel forms execute
+                    # fewer than the algorithmic count) against the f32 MFMA peak, and the kernel's algorithmic bytes against HBM
                     "executed_tflops": round(ach_exec, 3), "executed_frac_of_mfma_peak": round(ach_exec / PEAK_FP32_TFLOPS, 4),
+                    "hbm_gbs": round(top["bytes"] / (top["ms"] * 1e-3) / 1e9, 1) if top["ms"] > 0 else 0.0,
+                    "hbm_frac": round(top["bytes"] / (top["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if top["ms"] > 0 else 0.0,
                     "avg_launch_ms": round(top["ms"] / max(1, top["launches"]), 4),
                     "launches": top["launches"],
                     "measured": "HIP events around every launch in a second pass of the same K steps, run right "
