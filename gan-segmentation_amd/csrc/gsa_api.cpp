@@ -50,10 +50,10 @@ struct GenBlockDev {
 struct DecLevelDev {
     int F = 0, I = 0, in_c = 0, cs = 0;
     bool is_last = false, has_sc = false;
-    float *cvt_w = nullptr, *cvt_b = nullptr, *cvt_s = nullptr, *cvt_rm = nullptr, *cvt_beta = nullptr;
+    float *cvt_w = nullptr, *cvt_s = nullptr, *cvt_beta = nullptr;      // *_s, *_beta: bias + BatchNorm folded (load_bn)
     float *cvt_u = nullptr, *b_u = nullptr;   // Winograd forms of cvt / conv b, or null
-    float *a_w = nullptr, *a_b = nullptr, *a_s = nullptr, *a_rm = nullptr, *a_beta = nullptr;
-    float *b_w = nullptr, *b_b = nullptr, *b_s = nullptr, *b_rm = nullptr, *b_beta = nullptr;
+    float *a_w = nullptr, *a_s = nullptr, *a_beta = nullptr;
+    float *b_w = nullptr, *b_s = nullptr, *b_beta = nullptr;
     float *sc_w = nullptr, *sc_b = nullptr;
     float *f_w = nullptr, *f_b = nullptr;
 };
@@ -733,8 +733,10 @@ int gsa_decoder_set_param(gsa_ctx* c, const char* name, const float* data, int32
     return set_param(c, c->dparams, name, data, ndim, dims);
 }
 
-static int load_bn(gsa_ctx* c, const std::string& prefix, int C, float** s, float** rm, float** beta) {
-    std::vector<float> hs((size_t)C, 1.0f), hm((size_t)C, 0.0f), hb((size_t)C, 0.0f);
+// conv bias + inference BatchNorm folded into one fma per element (canonical arithmetic; reference networks_seg.py:14-32,
+// 68-76): s = gamma / sqrtf(running_var + 1e-5), k = fmaf(bias - running_mean, s, beta); use_bn=False: s = 1, k = bias
+static int load_bn(gsa_ctx* c, const std::string& prefix, int C, const float* bias, float** s, float** k) {
+    std::vector<float> hs((size_t)C, 1.0f), hk(bias, bias + C);
     if (c->d_bn) {
         const float *g, *b, *m, *v;
         NEED(c->dparams, prefix + ".gamma", (size_t)C, &g);
@@ -743,13 +745,11 @@ static int load_bn(gsa_ctx* c, const std::string& prefix, int C, float** s, floa
         NEED(c->dparams, prefix + ".running_var", (size_t)C, &v);
         for (int i = 0; i < C; ++i) {
             hs[i] = g[i] / std::sqrt(v[i] + 1e-5f);   // fp32: sqrtf, then one division
-            hm[i] = m[i];
-            hb[i] = b[i];
+            hk[i] = std::fmaf(bias[i] - m[i], hs[i], b[i]);
         }
     }
     if (int rc = upload(c, hs, s, c->d_allocs)) return rc;
-    if (int rc = upload(c, hm, rm, c->d_allocs)) return rc;
-    return upload(c, hb, beta, c->d_allocs);
+    return upload(c, hk, k, c->d_allocs);
 }
 
 int gsa_decoder_commit(gsa_ctx* c) {
@@ -780,10 +780,8 @@ int gsa_decoder_commit(gsa_ctx* c) {
             h = pack_wino(w, d.F, d.I, 1.0f, false, 1.0f);
             if (int rc = upload(c, h, &d.cvt_u, T)) return rc;
         }
-        h.assign(b, b + d.F);
-        if (int rc = upload(c, h, &d.cvt_b, T)) return rc;
         snprintf(nm, sizeof nm, "cvt_block_%d.1", i);
-        if (int rc = load_bn(c, nm, d.F, &d.cvt_s, &d.cvt_rm, &d.cvt_beta)) return rc;
+        if (int rc = load_bn(c, nm, d.F, b, &d.cvt_s, &d.cvt_beta)) return rc;
         if (!d.is_last) {
             const int second = c->d_bn ? 3 : 2;
             const std::string pf = "main_block_" + std::to_string(i) + ".1.base_layers";
@@ -791,9 +789,7 @@ int gsa_decoder_commit(gsa_ctx* c) {
             NEED(P, pf + ".0.bias", (size_t)d.cs, &b);
             h = (8 << i) >= 16 ? pack_upconv(w, d.cs, d.in_c, 1.0f, false, 1.0f) : pack_conv3(w, d.cs, d.in_c, 1.0f, false, 1.0f);
             if (int rc = upload_mfma(c, h, &d.a_w, T)) return rc;
-            h.assign(b, b + d.cs);
-            if (int rc = upload(c, h, &d.a_b, T)) return rc;
-            if (int rc = load_bn(c, pf + ".1", d.cs, &d.a_s, &d.a_rm, &d.a_beta)) return rc;
+            if (int rc = load_bn(c, pf + ".1", d.cs, b, &d.a_s, &d.a_beta)) return rc;
             NEED(P, pf + "." + std::to_string(second) + ".weight", (size_t)d.cs * d.cs * 9, &w);
             NEED(P, pf + "." + std::to_string(second) + ".bias", (size_t)d.cs, &b);
             h = pack_conv3(w, d.cs, d.cs, 1.0f, false, 1.0f);
@@ -802,9 +798,7 @@ int gsa_decoder_commit(gsa_ctx* c) {
                 h = pack_wino(w, d.cs, d.cs, 1.0f, false, 1.0f);
                 if (int rc = upload(c, h, &d.b_u, T)) return rc;
             }
-            h.assign(b, b + d.cs);
-            if (int rc = upload(c, h, &d.b_b, T)) return rc;
-            if (int rc = load_bn(c, pf + "." + std::to_string(second + 1), d.cs, &d.b_s, &d.b_rm, &d.b_beta)) return rc;
+            if (int rc = load_bn(c, pf + "." + std::to_string(second + 1), d.cs, b, &d.b_s, &d.b_beta)) return rc;
             d.has_sc = d.cs != d.in_c;
             if (d.has_sc) {
                 const std::string sc = "main_block_" + std::to_string(i) + ".1.shortcut.0";
@@ -1069,7 +1063,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             cp.src0 = fsrc[i]; cp.aff0 = faff ? faff[i] : nullptr; cp.C0 = d.I;
             cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
             cp.wpk = d.cvt_w; cp.wino = d.cvt_u; cp.Cout = d.F; cp.out = c->cvt[i];
-            cp.bias = d.cvt_b; cp.bn_s = d.cvt_s; cp.bn_rm = d.cvt_rm; cp.bn_beta = d.cvt_beta;
+            cp.bn_s = d.cvt_s; cp.bn_beta = d.cvt_beta;
             snprintf(layer, sizeof layer, "d.cvt_%d", i);
             Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * (conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px * (d.I + d.F), 2.0 * px * d.F * d.I * 9);
             HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
@@ -1083,7 +1077,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 else { cp.src0 = c->cvt[i]; cp.C0 = d.F; }
                 cp.Hs = R; cp.Ws = R; cp.up = 1; cp.H = R2; cp.W = R2;
                 cp.wpk = d.a_w; cp.Cout = d.cs; cp.out = c->ya[i];
-                cp.bias = d.a_b; cp.bn_s = d.a_s; cp.bn_rm = d.a_rm; cp.bn_beta = d.a_beta;
+                cp.bn_s = d.a_s; cp.bn_beta = d.a_beta;
                 if (d.has_sc) { cp.wsc = d.sc_w; cp.sc_bias = d.sc_b; cp.out_sc = c->scb[i]; }
                 snprintf(layer, sizeof layer, "d.main_%d.a", i);
                 if (R2 >= 16) {   // sub-pixel form: 4 taps per output instead of 9
@@ -1104,7 +1098,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 cp.src0 = c->ya[i]; cp.C0 = d.cs;
                 cp.Hs = R2; cp.Ws = R2; cp.H = R2; cp.W = R2;
                 cp.wpk = d.b_w; cp.wino = d.b_u; cp.Cout = d.cs; cp.out = c->prev[i];
-                cp.bias = d.b_b; cp.bn_s = d.b_s; cp.bn_rm = d.b_rm; cp.bn_beta = d.b_beta;
+                cp.bn_s = d.b_s; cp.bn_beta = d.b_beta;
                 if (d.has_sc) { cp.resid = c->scb[i]; cp.resid_up = R2 >= 16 ? 1 : 0; }   // sub-pixel conv a stores the shortcut at input resolution
                 else if (i == s0) { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 else { cp.resid = c->prev[i - 1]; cp.resid1 = c->cvt[i]; cp.res_c0 = d.F; cp.resid_up = 1; }   // ... over concat(prev, cvt)

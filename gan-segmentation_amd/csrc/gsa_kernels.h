@@ -33,8 +33,9 @@ struct ConvParams {
     // EPI_SYNTH: AddNoise -> Bias -> LeakyReLU -> statistics
     const float* noise; const float* nscale; const float* nbias;
     StatPart* partials; int prow;      // prow = partial rows per sample
-    // EPI_DEC: conv bias -> BatchNorm(inference) -> LeakyReLU [-> + resid]
-    const float* bias; const float* bn_s; const float* bn_rm; const float* bn_beta;
+    // EPI_DEC: conv bias -> BatchNorm(inference) -> LeakyReLU [-> + resid], folded on the host into ONE fma per element:
+    // y = lrelu(fmaf(v, bn_s, bn_beta)) with bn_s = gamma / sqrt(running_var + eps), bn_beta = fmaf(bias - running_mean, bn_s, beta)
+    const float* bn_s; const float* bn_beta;
     const float* resid; int resid_up;   // resid_up: residual lives at half resolution (identity shortcut)
     const float* resid1; int res_c0;    // residual = concat(resid [res_c0 channels], resid1 [Cout - res_c0]); resid1 null: one tensor
     // fused 1x1 shortcut of DecoderResBlock (second output)

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
             const int co = tc.g * COUT_T + (wn * NT + nt) * 16 + i16;
             e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = 0.f;
             if (EPI == EPI_SYNTH) { e0[nt] = p.nscale[co]; e1[nt] = p.nbias[co]; }
-            if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
+            if (EPI == EPI_DEC) { e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }      // BatchNorm folded: y = lrelu(fmaf(v, s, k))
             if (SC) scb[nt] = p.sc_bias[co];
         }
         if (EPI == EPI_DEC && has_resid) {
@@ -615,8 +615,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
                     if (EPI == EPI_DEC) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float yv = v[r] + e0[nt];
-                            v[r] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
+                            v[r] = lrelu(fmaf(v[r], e2[nt], e3[nt]));
                         }
                     }
                     f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
@@ -1057,11 +1056,10 @@ __global__ __launch_bounds__(256 * PS) void conv3x3_ksplit(ConvParams p) {
         }
     }
     if (EPI == EPI_DEC) {
-        const float e0 = p.bias[co], e1 = p.bn_rm[co], e2 = p.bn_s[co], e3 = p.bn_beta[co];
+        const float e2 = p.bn_s[co], e3 = p.bn_beta[co];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float yv = v[r] + e0;
-            v[r] = lrelu(fmaf(yv - e1, e2, e3));
+            v[r] = lrelu(fmaf(v[r], e2, e3));
         }
     }
     f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
@@ -1327,7 +1325,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         const int co = co0 + nt * 16 + i16;
         e0[nt] = e1[nt] = e2[nt] = e3[nt] = 0.f;
         if (EPI == EPI_SYNTH) { e0[nt] = p.nscale[co]; e1[nt] = p.nbias[co]; }
-        if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
+        if (EPI == EPI_DEC) { e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }      // BatchNorm folded: y = lrelu(fmaf(v, s, k))
     }
     auto epilogue_loads = [&](const Tile& tc) {
         if (EPI == EPI_SYNTH) {
@@ -1411,8 +1409,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
                 if (EPI == EPI_DEC) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float yv = v[k] + e0[nt];
-                        v[k] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
+                        v[k] = lrelu(fmaf(v[k], e2[nt], e3[nt]));
                     }
                 }
                 f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
@@ -1839,9 +1836,8 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 #pragma unroll
             for (int f = 0; f < 9; ++f) m[f] = acc[f][nt];
             wino22_output(m, y);
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+            f32x4 c2 = {0.f, 0.f, 0.f, 0.f}, c3 = c2;
             if (EPI == EPI_DEC) {
-                c0 = *reinterpret_cast<const f32x4*>(p.bias + co); c1 = *reinterpret_cast<const f32x4*>(p.bn_rm + co);
                 c2 = *reinterpret_cast<const f32x4*>(p.bn_s + co); c3 = *reinterpret_cast<const f32x4*>(p.bn_beta + co);
             }
 #pragma unroll
@@ -1849,7 +1845,7 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     f32x4 vt = y[a][b];
-                    if (EPI == EPI_DEC) vt = lrelu4(__builtin_elementwise_fma((vt + c0) - c1, c2, c3));
+                    if (EPI == EPI_DEC) vt = lrelu4(__builtin_elementwise_fma(vt, c2, c3));
                     const int oy = y0 + 2 * (2 * wty + a) + py, ox = x0 + 2 * (2 * wtx + b) + px;
                     act_store4<false>(p.out, ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + co, vt);
                 }
@@ -1860,7 +1856,7 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
     for (int nt = 0; nt < NT; ++nt) {
         const int co = g * COUT_T + nt * 16 + i16;
         e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = 0.f;
-        if (EPI == EPI_DEC) { e0[nt] = p.bias[co]; e1[nt] = p.bn_rm[co]; e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }
+        if (EPI == EPI_DEC) { e2[nt] = p.bn_s[co]; e3[nt] = p.bn_beta[co]; }      // BatchNorm folded: y = lrelu(fmaf(v, s, k))
         if (SC) scb[nt] = p.sc_bias[co];
     }
     // stores in the quad-transposed layout: lane -> (x = lane&3, channels 4*((lane>>2)&3)..+3), 16 bytes each
@@ -1878,8 +1874,7 @@ __global__ __launch_bounds__(256) void subpixel_mfma(ConvParams p) {
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[mt][nt][r];
                 if (EPI == EPI_DEC) {
-                    const float yv = v[r] + e0[nt];
-                    v[r] = lrelu(fmaf(yv - e1[nt], e2[nt], e3[nt]));
+                    v[r] = lrelu(fmaf(v[r], e2[nt], e3[nt]));
                 }
             }
             const f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
@@ -2027,7 +2022,6 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
         const int co = g * 16 * NT + nt * 16 + 4 * (lane >> 4);
         e0[nt] = e1[nt] = e2[nt] = e3[nt] = scb[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI == EPI_DEC) {
-            e0[nt] = *reinterpret_cast<const f32x4*>(p.bias + co); e1[nt] = *reinterpret_cast<const f32x4*>(p.bn_rm + co);
             e2[nt] = *reinterpret_cast<const f32x4*>(p.bn_s + co); e3[nt] = *reinterpret_cast<const f32x4*>(p.bn_beta + co);
         }
         if (SC) scb[nt] = *reinterpret_cast<const f32x4*>(p.sc_bias + co);
@@ -2149,8 +2143,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
                 for (int mt = 0; mt < 4; ++mt) {       // the tile's 2x2 class outputs (a, b) = (mt >> 1, mt & 1)
                     f32x4 vt = y[mt >> 1][mt & 1];
                     if (EPI == EPI_DEC) {
-                        const f32x4 yv = vt + e0[nt];
-                        vt = lrelu4(__builtin_elementwise_fma(yv - e1[nt], e2[nt], e3[nt]));
+                        vt = lrelu4(__builtin_elementwise_fma(vt, e2[nt], e3[nt]));
                     }
                     const size_t ubase = ((size_t)(t.n * p.H + t.y0 + 2 * (mt >> 1) + py) * p.W + t.x0 + 2 * (mt & 1) + px) * p.Cout + g * 16 * NT + nt * 16;
                     act_store4<false>(p.out, ubase + lane_out, vt);
@@ -2160,8 +2153,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
             for (int mt = 0; mt < 4; ++mt) {
                 f32x4 vt = acc[mt][nt];
                 if (EPI == EPI_DEC) {
-                    const f32x4 yv = vt + e0[nt];
-                    vt = lrelu4(__builtin_elementwise_fma(yv - e1[nt], e2[nt], e3[nt]));
+                    vt = lrelu4(__builtin_elementwise_fma(vt, e2[nt], e3[nt]));
                 }
                 const size_t ubase = ((size_t)(t.n * p.H + t.y0 + 8 * (mt >> 1) + py) * p.W + t.x0 + 8 * (mt & 1) + px) * p.Cout + g * 16 * NT + nt * 16;
                 act_store4<BF>(p.out, ubase + lane_out, vt);
@@ -2351,7 +2343,10 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
     const int total = (p.H / RPT) * W4 * C4;
     for (int i = threadIdx.x; i < 2 * p.C; i += 256) sstat[i] = 0ull;
     __syncthreads();
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware block order (workgroup b runs on XCD b % 8): XCD x takes the x-th contiguous eighth of the row groups, so the two
+    // halo rows a row group shares with its neighbours come out of that XCD's L2 instead of being fetched once more from HBM by
+    // another XCD (rocprofv3, round 2: 1.29x the algorithmic bytes with row groups dealt round-robin)
+    const int idx = xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (idx < total) {
         const int cq = idx % C4, t = idx / C4;
         const int xq = t % W4, y0 = (t / W4) * RPT;

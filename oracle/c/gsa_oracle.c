@@ -1066,8 +1066,10 @@ static void bias_bn_act(float* x, size_t npix, int C, const float* bias, const f
 #pragma omp parallel for schedule(static)
     for (size_t p = 0; p < npix; ++p)
         for (int c = 0; c < C; ++c) {
-            float y = x[p * C + c] + bias[c];
-            x[p * C + c] = lrelu(fmaf(y - rm[c], s[c], beta[c]));
+            /* conv bias + inference BatchNorm folded into ONE fma per element (round 3): k = fmaf(bias - running_mean, s, beta)
+             * per channel, y = lrelu(fmaf(x, s, k)); reference networks_seg.py:14-32, 68-76 (use_bn=False: s = 1, k = bias) */
+            const float k = fmaf(bias[c] - rm[c], s[c], beta[c]);
+            x[p * C + c] = lrelu(fmaf(x[p * C + c], s[c], k));
         }
 }
 
