@@ -328,7 +328,7 @@ std::vector<float> pack_wino(const float* w, int O, int I, float std, bool us, f
 
 // the static rule of the Winograd form (gsa_kernels.hip conv_uses_wino): plain 3x3 convs with outputs >= 64 px, or >= 32 px with
 // at least 64 output channels (fewer tiles than that leave the chip idle: the direct small-tile kernels are faster there), fp32 mode
-inline bool wino_layer(const gsa_ctx* c, int R, int Cout) { return !c->bf16 && (R >= 64 || (R >= 32 && Cout >= 64)); }
+inline bool wino_layer(const gsa_ctx* c, int R, int Cout) { return !c->bf16 && (R >= 64 || (R >= 32 && Cout >= 64) || (R >= 16 && Cout >= 256)); }
 
 // final conv (K,I,3,3) -> [cb][tap][c16][K]
 std::vector<float> pack_final(const float* w, int K, int I) {

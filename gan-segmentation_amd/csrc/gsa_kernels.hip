@@ -3310,7 +3310,7 @@ static hipError_t launch_ksplit(const ConvParams& p, int epi, int n, hipStream_t
 bool conv_uses_wino(const ConvParams& p, int epi, bool sc) {
     static const bool enabled = !(getenv("GSA_WINO") && atoi(getenv("GSA_WINO")) == 0);
     return enabled && p.wino != nullptr && !p.bf16 && !sc && !p.up && p.src1 == nullptr && p.C1 == 0 && epi != EPI_RAW &&
-           (p.H >= 64 || (p.H >= 32 && p.Cout >= 64)) && p.H == p.W && p.H % 16 == 0 && p.Cout % 16 == 0 && p.C0 % 16 == 0;
+           (p.H >= 64 || (p.H >= 32 && p.Cout >= 64) || (p.H >= 16 && p.Cout >= 256)) && p.H == p.W && p.H % 16 == 0 && p.Cout % 16 == 0 && p.C0 % 16 == 0;
 }
 
 // output channels per workgroup = 16*NT.  NT = 2 (one workgroup per CU with the whole register file, the input transform and

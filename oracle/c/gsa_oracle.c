@@ -256,7 +256,7 @@ static float* pack_upconv(const float* w, int O, int I, float std, int use_std, 
 static int g_wino_enabled = -1;
 static int use_wino(int H, int W, int Cout, int up, int bf) {
     if (g_wino_enabled < 0) { const char* e = getenv("GSAO_WINO"); g_wino_enabled = !(e && atoi(e) == 0); }
-    return g_wino_enabled && !bf && !up && H == W && (H >= 64 || (H >= 32 && Cout >= 64)) && H % 16 == 0;
+    return g_wino_enabled && !bf && !up && H == W && (H >= 64 || (H >= 32 && Cout >= 64) || (H >= 16 && Cout >= 256)) && H % 16 == 0;
 }
 
 /* conv OIHW (O,I,3,3) -> U packed [(cb*16 + f)*CB + c][O], f = 4*i + j */
