@@ -62,11 +62,11 @@ def test_bf16_reduced_against_bf16_oracle_and_fp32(torch_cuda, oracle_lib):
     _logits_o, mask_o = o.decoder(feats_o)
     mx, _ = _rel(feats[0], feats_o[0])
     assert mx <= 2e-6, "4x4 level must agree with the bf16 oracle to fp32 rounding, got %.3e" % mx
-    _check_against(rgb, mask, rgb_o, mask_o, 3e-2, 3e-3, 0.995, "bf16 HIP vs bf16 oracle")
+    _check_against(rgb, mask, rgb_o, mask_o, 2e-2, 2e-3, 0.997, "bf16 HIP vs bf16 oracle")       # measured 0.4 % / 0.011 % / 99.97 %
     # the mode really is a different arithmetic, and stays close to the canonical fp32 path
     rgb32, _f32, img32, mask32 = _run(_build(setup, 3, "fp32"), z, noise)
     assert not np.array_equal(rgb, rgb32)
-    _check_against(rgb, mask, rgb32, mask32, 6e-2, 6e-3, 0.99, "bf16 HIP vs fp32 HIP")
+    _check_against(rgb, mask, rgb32, mask32, 6e-2, 6e-3, 0.99, "bf16 HIP vs fp32 HIP")                # measured 4.8 % / 0.29 % / 99.72 % (128 px, 3 samples)
     o32 = oracle_lib.Oracle(gcfg, gp, dcfg, dp)
     assert np.array_equal(o32.generator(z, noise)[0], rgb32), "the fp32 context next to a bf16 one stays bit-exact"
 
@@ -107,10 +107,10 @@ def test_config5_cars_512_bf16(torch_cuda, oracle_lib):
     o = oracle_lib.Oracle(gcfg, gp, dcfg, dp, precision="bf16")
     rgb_o, img_o, feats_o = o.generator(z[:1], [a[:1] for a in noise])
     _logits_o, mask_o = o.decoder(feats_o)
-    _check_against(rgb[:1], mask2[:1], rgb_o, mask_o, 3e-2, 3e-3, 0.995, "cars bf16 HIP vs bf16 oracle")
+    _check_against(rgb[:1], mask2[:1], rgb_o, mask_o, 2e-2, 2e-3, 0.997, "cars bf16 HIP vs bf16 oracle")   # measured 1.4 % / 0.13 % / 99.80 %
     assert np.abs(img2[:1].astype(np.int32) - img_o.astype(np.int32)).mean() <= 2.0   # u8 image: mean error <= 2 levels
     rgb32, _f, img32, mask32 = _run(_build(setup, 4, "fp32"), z, noise)
-    _check_against(rgb, mask2, rgb32, mask32, 6e-2, 6e-3, 0.99, "cars bf16 HIP vs fp32 HIP")
+    _check_against(rgb, mask2, rgb32, mask32, 4.5e-2, 4e-3, 0.993, "cars bf16 HIP vs fp32 HIP")          # measured 3.3 % / 0.25 % / 99.57 %
     # the fp32 path at this batch (4096 tiles at 512^2: the persistent resident-weight kernels are in use) stays bit-exact
     o32 = oracle_lib.Oracle(gcfg, gp, dcfg, dp)
     img_o32, mask_o32 = o32.generate(z[3:], [a[3:] for a in noise])
