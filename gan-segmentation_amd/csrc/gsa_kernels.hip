@@ -1140,22 +1140,28 @@ __device__ __forceinline__ void mfma_settle(f32x4 (&a)[16]) {
 // CHUNK = staging by 16-byte chunks with the AdaIN coefficients in registers (see "staging by 16-byte chunks" above): measured
 // faster for the layers with >= 64 input channels (g.64 / g.128 / g.256.conv_2 -4..-9 %), slower for the resident-weight layers
 // with <= 32 (d.main_6.b +11 %, d.cvt_8 +5 %), which therefore keep whole-pixel staging with a two-slot LDS coefficient table.
-template <int EPI, int NT, bool CHUNK, bool AFF>      // AFF: the source carries AdaIN coefficients (p.aff0 != null) -- compile time, so that the
-__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams p) {      // instantiations without it carry none of its code
-    constexpr int NTHR = 256, LH = 18, LW = 18, RS = LW * 16 + 4;
+// GW = output-channel groups per workgroup (round 3): GW = 2 is a 512-thread workgroup whose waves 0-3 / 4-7 multiply the SAME staged
+// activation image by the weights of two neighbouring 16-channel groups -- a layer with several groups stages (loads, AdaIN, LDS
+// writes) every input tile once per group, so sharing the image between two groups halves that work per MFMA; occupancy is
+// unchanged (one 8-wave workgroup per CU instead of two 4-wave ones).  Same arithmetic per output: same bits.
+template <int EPI, int NT, bool CHUNK, bool AFF, int GW = 1>      // AFF: the source carries AdaIN coefficients (p.aff0 != null) -- compile time, so that the
+__global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams p) {      // instantiations without it carry none of its code
+    constexpr int NTHR = 256 * GW, LH = 18, LW = 18, RS = LW * 16 + 4;
     constexpr int SEG = 16 * 256;                // U floats per (16 couts, 16-channel block): 16 frequencies x [ci][16][cg]
-    constexpr int NB4 = SEG / 4, BIT = NT * NB4 / NTHR;      // 16-byte pieces of one (16 couts, block) segment; pieces per thread of a block
+    constexpr int NB4 = SEG / 4, BIT = NT * NB4 / 256;      // 16-byte pieces of one (16 couts, block) segment; pieces per thread of a block
     constexpr int NCH = CHUNK ? (LH * LW * 4 + NTHR - 1) / NTHR : (LH * LW + NTHR - 1) / NTHR;     // staging rounds per item (chunks or pixels)
     constexpr int RW = CHUNK ? 1 : 4;                        // 16-byte registers per staged unit
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nblk = p.C0 >> 4;
     const bool wres = p.w_resident != 0;
     float* sA = smem;                            // [2][LH*RS]
-    float* sB = sA + 2 * LH * RS;                // resident: [nblk][NT][SEG]; streamed: [2][NT][SEG]
-    f32x4* sAff = reinterpret_cast<f32x4*>(sB + (wres ? nblk : 2) * NT * SEG);   // !CHUNK: [2][16] (mean, A, B, -)
+    float* sB = sA + 2 * LH * RS;                // resident: [GW][nblk][NT][SEG]; streamed: [2][GW][NT][SEG]
+    f32x4* sAff = reinterpret_cast<f32x4*>(sB + (wres ? nblk : 2) * GW * NT * SEG);   // !CHUNK: [2][16] (mean, A, B, -)
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, gsel = wave8 >> 2;      // quadrant of the tile; which of the workgroup's GW channel groups
+    const int tid8 = tid & 255;                         // thread index inside its group's 256 threads (weight staging)
     const int i16 = lane & 15, kq = lane >> 4;
     // group_minor (launcher: one tile per workgroup, several channel groups, all weight panels together small enough for an
     // XCD's L2): a 1-D grid in which the G groups of ONE tile are consecutive workgroups of ONE XCD (workgroup b runs on XCD
@@ -1164,12 +1170,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
     int g, w_begin, w_end;
     if (p.group_minor) {
         const int b = blockIdx.x, j = b >> 3;
-        g = j % p.groups;
+        g = (j % p.groups) * GW + gsel;
         w_begin = (j / p.groups) * 8 + (b & 7);
         w_end = w_begin + 1;
     } else {
         // contiguous range of the group's tiles, order (n, ty, tx)
-        g = blockIdx.y;
+        g = (int)blockIdx.y * GW + gsel;
         const int chunk = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
         w_begin = xcd_block(blockIdx.x, gridDim.x) * chunk;
         w_end = min(p.total_tiles, w_begin + chunk);
@@ -1233,7 +1239,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
     int wsrc[BIT];                                   // this thread's pieces of a block: q*nblk*SEG + 4r floats
 #pragma unroll
     for (int j = 0; j < BIT; ++j) {
-        const int i = tid + j * NTHR;
+        const int i = tid8 + j * 256;
         wsrc[j] = (i / NB4) * nblk * SEG + (i % NB4) * 4;
     }
     auto load_item = [&](const Tile& t, int cb, const Chunk (&tp)[NCH]) {
@@ -1303,7 +1309,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
         }
         if (!wres) {
 #pragma unroll
-            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + buf * (NT * SEG))[tid + j * NTHR] = rb[j];
+            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + (buf * GW + gsel) * (NT * SEG))[tid8 + j * 256] = rb[j];
         }
     };
 
@@ -1435,7 +1441,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
     auto wino_item = [&](int buf, int cb_res) {
         __builtin_amdgcn_s_setprio(GSA_MFMA_PRIO);
         const float* a_img = sA + buf * (LH * RS) + pbase;
-        const float* b_img = sB + (wres ? cb_res : buf) * (NT * SEG) + bbase;
+        const float* b_img = sB + (wres ? gsel * nblk + cb_res : buf * GW + gsel) * (NT * SEG) + bbase;
         // input transform V = B^T d B on the lane's 4x4 patch, four channels (cg) per vector:
         //   rows  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3;   columns: the same four forms
         f32x4 V[16];
@@ -1498,7 +1504,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams 
 #pragma unroll
             for (int j = 0; j < BIT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wgrp + (size_t)cbk * SEG + wsrc[j]);
 #pragma unroll
-            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + cbk * (NT * SEG))[tid + j * NTHR] = rb[j];
+            for (int j = 0; j < BIT; ++j) reinterpret_cast<f32x4*>(sB + (gsel * nblk + cbk) * (NT * SEG))[tid8 + j * 256] = rb[j];
         }
     }
     load_item(tc, cb, tpr);
@@ -3321,13 +3327,13 @@ static int wino_nt(const ConvParams& p) {
     return (forced >= 2 && p.Cout % 32 == 0) ? 2 : 1;
 }
 
-template <int EPI, int NT, bool CHUNK, bool AFF>
+template <int EPI, int NT, bool CHUNK, bool AFF, int GW>
 static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int RS = 18 * 16 + 4, SEG = 16 * 256;
     const int nblk = p.C0 / 16;
     const bool wres = (size_t)nblk * NT * SEG * sizeof(float) <= (NT == 1 ? 36 : 72) * 1024;      // whole panel of the group resident (<= 32 input channels)
-    const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * NT * SEG) + (CHUNK ? 0 : 32 * sizeof(float4));
-    auto kern = conv3x3_wino<EPI, NT, CHUNK, AFF>;
+    const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * GW * NT * SEG) + (CHUNK ? 0 : 32 * sizeof(float4));
+    auto kern = conv3x3_wino<EPI, NT, CHUNK, AFF, GW>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
     int num_cus = 0, wgs_per_cu = 0;
@@ -3341,11 +3347,11 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
             if (st.occ_lds[i] == lds) wgs_per_cu = st.occ_k[i];
         if (!wgs_per_cu) {
             int k = 0;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, reinterpret_cast<const void*>(kern), 256, lds);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, reinterpret_cast<const void*>(kern), 256 * GW, lds);
             if (e != hipSuccess) return e;
             wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
             if (st.occ_n < 8) { st.occ_lds[st.occ_n] = lds; st.occ_k[st.occ_n] = wgs_per_cu; ++st.occ_n; }
-            if (getenv("GSA_VERBOSE")) fprintf(stderr, "gsa: conv3x3_wino<%d,%d,%d,%d> lds %zu B%s -> %d workgroups/CU\n", EPI, NT, (int)CHUNK, (int)AFF, lds, wres ? " (resident weights)" : "", k);
+            if (getenv("GSA_VERBOSE")) fprintf(stderr, "gsa: conv3x3_wino<%d,%d,%d,%d,%d> lds %zu B%s -> %d workgroups/CU\n", EPI, NT, (int)CHUNK, (int)AFF, GW, lds, wres ? " (resident weights)" : "", k);
         }
     }
     ConvParams q = p;
@@ -3353,7 +3359,7 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     q.w_resident = wres ? 1 : 0;
     q.tiles_x = p.W / 16;
     q.tiles_y = p.H / 16;
-    q.groups = p.Cout / (16 * NT);
+    q.groups = p.Cout / (16 * NT * GW);      // workgroup-level groups: GW channel groups of 16*NT each per workgroup
     q.prow = q.tiles_x * q.tiles_y * 4;
     q.total_tiles = q.tiles_x * q.tiles_y * n;         // per output-channel group
     // persistent workgroups for short tiles (<= 2 channel blocks); a workgroup stays inside its channel group
@@ -3370,8 +3376,8 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     static const bool gm_enabled = !(getenv("GSA_WINO_GM") && atoi(getenv("GSA_WINO_GM")) == 0);
     q.group_minor = (gm_enabled && !persistent && q.groups > 1 && q.total_tiles % 8 == 0 &&
                      (size_t)16 * p.C0 * p.Cout * sizeof(float) <= (size_t)2 << 20) ? 1 : 0;
-    if (q.group_minor) hipLaunchKernelGGL(kern, dim3(q.total_tiles * q.groups), dim3(256), lds, s, q);
-    else hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256), lds, s, q);
+    if (q.group_minor) hipLaunchKernelGGL(kern, dim3(q.total_tiles * q.groups), dim3(256 * GW), lds, s, q);
+    else hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256 * GW), lds, s, q);
     return hipGetLastError();
 }
 
@@ -3381,12 +3387,25 @@ static bool wino_chunk(const ConvParams& p) {
     return forced >= 0 ? forced != 0 : p.C0 >= 64;
 }
 
+// channel groups per workgroup: 2 (one staged image multiplied by two groups' weights) for the layers with an LDS-resident weight
+// panel (<= 32 input channels) and an even number of 16-channel groups -- measured (FFHQ batch 8, same box): d.cvt_7 0.262 -> 0.233 ms,
+// g.512.conv_2 0.279 -> 0.255, d.main_6.b unchanged; the streamed-weight layers (chunk staging, >= 64 input channels) were 2-10 %
+// SLOWER with it (g.32...g.256.conv_2 0.234/0.237/0.248/0.294 -> 0.256/0.257/0.253/0.298: their eight waves then wait on one
+// barrier for a 32 KB weight block per item) and keep one group per workgroup.  GSA_WINO_GW=1 / 2 force it (speed only, same bits).
+static int wino_gw(const ConvParams& p) {
+    static const int forced = getenv("GSA_WINO_GW") ? atoi(getenv("GSA_WINO_GW")) : 0;
+    if (wino_nt(p) != 1 || p.Cout % 32 != 0 || forced == 1) return 1;
+    return (forced >= 2 || p.C0 <= 32) ? 2 : 1;
+}
+
 static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s) {
     const int nt = wino_nt(p);
+    const int gw = wino_gw(p);
     const bool ch = wino_chunk(p);
 #define GSA_W(EPI, AFF) \
-    if (nt == 2) return ch ? launch_wino_t<EPI, 2, true, AFF>(p, n, s) : launch_wino_t<EPI, 2, false, AFF>(p, n, s); \
-    return ch ? launch_wino_t<EPI, 1, true, AFF>(p, n, s) : launch_wino_t<EPI, 1, false, AFF>(p, n, s);
+    if (nt == 2) return ch ? launch_wino_t<EPI, 2, true, AFF, 1>(p, n, s) : launch_wino_t<EPI, 2, false, AFF, 1>(p, n, s); \
+    if (gw == 2) return ch ? launch_wino_t<EPI, 1, true, AFF, 2>(p, n, s) : launch_wino_t<EPI, 1, false, AFF, 2>(p, n, s); \
+    return ch ? launch_wino_t<EPI, 1, true, AFF, 1>(p, n, s) : launch_wino_t<EPI, 1, false, AFF, 1>(p, n, s);
     if (epi == EPI_SYNTH) {
         if (p.aff0) { GSA_W(EPI_SYNTH, true) }
         GSA_W(EPI_SYNTH, false)
@@ -3400,7 +3419,7 @@ static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s
 const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     static thread_local char buf[128];
     if (conv_uses_wino(p, epi, sc)) {
-        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d, %d, %s, %s>(gsa::ConvParams)", epi, wino_nt(p), wino_chunk(p) ? "true" : "false", p.aff0 ? "true" : "false");
+        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d, %d, %s, %s, %d>(gsa::ConvParams)", epi, wino_nt(p), wino_chunk(p) ? "true" : "false", p.aff0 ? "true" : "false", wino_gw(p));
         return buf;
     }
     if (conv_uses_ksplit(p, sc)) {
