@@ -130,6 +130,10 @@ class Context:
         self.decoder_cfg = None
         self.precision = "fp32"
         self._checked_first_step = False
+        # hipGraph replay of small steps (image_generator._generate_on): graphs bake in the workspace pointers, the stream
+        # structure (set_overlap) and must not contain profiling events -- any of these changing starts a new epoch
+        self.graph_epoch = 0
+        self.profiling = False
 
     def _msg(self, h):
         m = self.api.last_error(h)
@@ -208,6 +212,7 @@ class Context:
         self._check(self.api.decoder_commit(self._h), "decoder_commit")
 
     def reserve(self, max_batch):
+        self.graph_epoch += 1
         self._check(self.api.reserve(self._h, int(max_batch)), "reserve")
 
     # -- forward calls: every tensor argument is a raw address (int) or None -------------
@@ -240,10 +245,13 @@ class Context:
                     "segmentation_eval")
 
     def set_overlap(self, levels):
+        self.graph_epoch += 1
         self._check(self.api.set_overlap(self._h, int(levels)), "set_overlap")
 
     # -- measurement ----------------------------------------------------------------------
     def profile_enable(self, on=True):
+        self.graph_epoch += 1
+        self.profiling = bool(int(on))
         self._check(self.api.profile_enable(self._h, int(on)), "profile_enable")
 
     def profile_reset(self):

@@ -623,6 +623,41 @@ def test_device_side_checks_are_reported(torch_cuda, oracle_lib, monkeypatch):
     assert "hipcc" in ctx.api.version().decode() and "clang" in ctx.api.version().decode()
 
 
+
+def test_graph_replay_of_small_steps_matches_the_oracle(torch_cuda, oracle_lib, monkeypatch):
+    """`generate_batch` replays a captured hipGraph when the very same call repeats (small batches / bf16 mode; GSA_GRAPH=1 forces
+    it): the replay must read the CURRENT contents of the input tensors and write the current outputs -- same bytes as the
+    eager call and as the oracle, also after the inputs were rewritten in place and after the workspace was re-reserved."""
+    monkeypatch.setenv("GSA_GRAPH", "1")
+    gcfg, gp, dcfg, dp, z, noise = reduced_setup(7, batch=4, trivial_norm=False)
+    o = oracle_lib.Oracle(gcfg, gp, dcfg, dp)
+    want = [o.generate(z[k:k + 2], [a[k:k + 2] for a in noise]) for k in (0, 2)]
+    gen = _build(gcfg, gp, dcfg, dp, 2)
+    zt = torch_cuda.from_numpy(z[:2].copy()).cuda()
+    nt = [torch_cuda.from_numpy(a[:2].copy()).cuda() for a in noise]
+    out = (torch_cuda.empty((2, 128, 128, 3), dtype=torch_cuda.uint8, device="cuda"),
+           torch_cuda.empty((2, 128, 128), dtype=torch_cuda.uint8, device="cuda"))
+    model = gen.netG._model
+    for it in range(8):
+        k = 0 if it % 2 == 0 else 2                      # the SAME tensors, rewritten in place: the key does not change
+        zt.copy_(torch_cuda.from_numpy(z[k:k + 2].copy()))
+        for t, a in zip(nt, noise):
+            t.copy_(torch_cuda.from_numpy(a[k:k + 2].copy()))
+        out[0].zero_(); out[1].zero_()
+        img, mask = gen.generate_batch(zt, nt, out=out)
+        assert_same(img.cpu().numpy(), want[k // 2][0], "image, call %d" % it)
+        assert_same(mask.cpu().numpy(), want[k // 2][1], "mask, call %d" % it)
+    assert len(model.__dict__.get("_graphs", {})) == 1, "the repeated call was never captured"
+    # a larger batch re-reserves the workspace: the old graph's pointers are stale and must not be replayed
+    gen4 = gen.generate_batch(z, noise)
+    img, mask = gen.generate_batch(zt, nt, out=out)
+    assert_same(img.cpu().numpy(), want[1][0], "image after re-reserve")
+    assert gen4[0].shape[0] == 4
+    monkeypatch.setenv("GSA_GRAPH", "0")
+    img, mask = gen.generate_batch(zt, nt, out=out)
+    assert_same(mask.cpu().numpy(), want[1][1], "mask, eager again")
+
+
 _SWITCH_WORKER = r'''
 import sys
 sys.path.insert(0, ROOT_DIR)
