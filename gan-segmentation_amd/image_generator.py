@@ -195,8 +195,8 @@ class ImageGenerator:
         nptrs = [a.data_ptr() for a in noise]
         if self._graph_wanted(model, n):
             # A small step is a latency chain of ~100 launches of 10-60 us: when the very same call comes again (same batch,
-            # same input and output addresses -- a steady loop over preallocated or recycled tensors) it is replayed from a
-            # captured hipGraph (+2-3 % at batch <= 2 and in bf16 mode; nothing at batch 8, where it stays eager).  The key holds
+            # same input and output addresses -- a steady loop over preallocated or recycled tensors) often enough it is replayed
+            # from a captured hipGraph (+2-3 % at batch <= 2 and in bf16 mode; nothing at batch 8, where it stays eager).  The key holds
             # every pointer the graph bakes in, so a replay always reads the current inputs and writes the current outputs.
             key = (n, z.data_ptr(), tuple(nptrs), img.data_ptr(), mask.data_ptr(), torch.cuda.current_stream(dev).cuda_stream,
                    model.ctx.graph_epoch)
@@ -207,7 +207,9 @@ class ImageGenerator:
                 return img, mask
             seen = model.__dict__.setdefault("_graph_seen", {})
             seen[key] = seen.get(key, 0) + 1
-            if seen[key] >= 3 and model.ctx._checked_first_step:      # third identical call: capture (never the context's first step)
+            # Capturing costs several milliseconds (about as much as five steps): a call is captured only after it has come 32 times
+            # -- a steady loop (main.py generate: thousands of steps), never a short benchmark or a one-off call
+            if seen[key] >= 32 and model.ctx._checked_first_step:
                 if len(cache) >= 8:
                     cache.pop(next(iter(cache)))
                 if len(seen) > 64:

@@ -638,7 +638,7 @@ def test_graph_replay_of_small_steps_matches_the_oracle(torch_cuda, oracle_lib, 
     out = (torch_cuda.empty((2, 128, 128, 3), dtype=torch_cuda.uint8, device="cuda"),
            torch_cuda.empty((2, 128, 128), dtype=torch_cuda.uint8, device="cuda"))
     model = gen.netG._model
-    for it in range(8):
+    for it in range(40):                                 # the 32nd identical call is captured, the later ones are replays
         k = 0 if it % 2 == 0 else 2                      # the SAME tensors, rewritten in place: the key does not change
         zt.copy_(torch_cuda.from_numpy(z[k:k + 2].copy()))
         for t, a in zip(nt, noise):
