@@ -3366,9 +3366,15 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     q.groups = p.Cout / (16 * NT * GW);      // workgroup-level groups: GW channel groups of 16*NT each per workgroup
     q.prow = q.tiles_x * q.tiles_y * 4;
     q.total_tiles = q.tiles_x * q.tiles_y * n;         // per output-channel group
-    // persistent workgroups for short tiles (<= 2 channel blocks); a workgroup stays inside its channel group
+    // persistent workgroups; a workgroup stays inside its channel group
     const int slots = std::max(1, num_cus * wgs_per_cu / q.groups);
-    const bool persistent = p.C0 <= 32 && q.total_tiles > slots;
+    // Round 3: persistent for EVERY channel count (round 2: only tiles of <= 2 channel blocks).  A one-tile workgroup pays its cold
+    // start -- first loads out of HBM, nothing to overlap them with -- per tile; a workgroup that walks a contiguous tile range keeps
+    // its two-item prefetch full across tiles: g.256.conv_2 0.292 -> 0.249 ms, d.cvt_6 0.150 -> 0.133, g.128.conv_2 0.247 -> 0.233,
+    // g.64 / g.32.conv_2 0.233 / 0.229 -> 0.224 / 0.225 (same box).  The groups of a tile range still meet in one XCD's L2: workgroup
+    // (x, g) has the linear index x + g * gx and gx is a multiple of 8.  GSA_WINO_PERS=<max input channels> restores a limit.
+    static const int pers_c = getenv("GSA_WINO_PERS") ? atoi(getenv("GSA_WINO_PERS")) : 1 << 30;
+    const bool persistent = p.C0 <= pers_c && q.total_tiles > slots;
     const int gx = persistent ? slots : q.total_tiles;
     static const bool direct_enabled = !(getenv("GSA_STATS_DIRECT") && atoi(getenv("GSA_STATS_DIRECT")) == 0);
     // direct statistics: always for persistent workgroups; for one-tile workgroups when the layer would otherwise write
