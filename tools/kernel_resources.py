@@ -8,7 +8,7 @@ txt = open(sys.argv[1]).read()
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 names, rows = [], []
 for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
-    name = b.split("\n")[0].strip()
+    name = b.split("\n")[0].strip().split(" ")[0]      # the mangled name (the remark flag follows it)
 
     def g(k):
         m = re.search(k + r": (\d+)", b)
