@@ -376,6 +376,9 @@ def main():
                     "hbm_frac": round(top["bytes"] / (top["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if top["ms"] > 0 else 0.0,
                     "avg_launch_ms": round(top["ms"] / max(1, top["launches"]), 4),
                     "launches": top["launches"],
+                    "note": "frac = ALGORITHMIC FLOP of the layer in the reference's formulation (SURVEY.md 8d) / time / peak, as the bench "
+                            "contract prescribes: a throughput in the reference's units that exceeds 1.0 for a Winograd kernel; the "
+                            "utilisation of the matrix pipe is executed_frac_of_mfma_peak",
                     "measured": "HIP events around every launch in a second pass of the same K steps, run right "
                                 "after the timed region with the decoder-beside-synthesis stream overlap off "
                                 "(durations not stretched by a concurrent kernel)",
