@@ -59,6 +59,7 @@ struct PostParams {
     float* out; StatPart* partials; int prow;
     int H, W, C;
     int bf16;              // 1: the per-sample source and the output are bf16 tensors (bf16 mode)
+    int row_groups;        // filled by the launcher (post_rows_kernel<4>): groups of 4 rows a thread walks
 };
 
 struct FinalizeParams {

@@ -2346,7 +2346,11 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sstat[];   // [2][C]
     const int n = blockIdx.y;
     const int C4 = p.C >> 2, W4 = p.W >> 2;
-    const int total = (p.H / RPT) * W4 * C4;
+    // row_groups (launcher; RPT = 4 only: the four-row ring then repeats per group): a thread walks row_groups * RPT consecutive rows
+    // with the window carried over -- RPT + 2 rows were loaded per RPT output rows, now RPT * NG + 2 per RPT * NG (6 loads per new row in
+    // both: 1.5x -> 1.125x load instructions at NG = 4) and a quarter of the threads pay the cold start of their first three rows
+    const int NG = p.row_groups > 1 ? p.row_groups : 1;
+    const int total = (p.H / (RPT * NG)) * W4 * C4;
     for (int i = threadIdx.x; i < 2 * p.C; i += 256) sstat[i] = 0ull;
     __syncthreads();
     // XCD-aware block order (workgroup b runs on XCD b % 8): XCD x takes the x-th contiguous eighth of the row groups, so the two
@@ -2355,7 +2359,7 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
     const int idx = xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (idx < total) {
         const int cq = idx % C4, t = idx / C4;
-        const int xq = t % W4, y0 = (t / W4) * RPT;
+        const int xq = t % W4, y0 = (t / W4) * (RPT * NG);
         const int c = cq * 4, x0 = xq * 4;
         const size_t sbase = (size_t)n * p.H * p.W * p.C + c;
         float wk[4][9];
@@ -2390,10 +2394,11 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
         load_row(win[1], y0);
         load_row(win[2], y0 + 1);
         unsigned long long I1[4] = {0, 0, 0, 0}, I2[4] = {0, 0, 0, 0};
+        for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            const int y = y0 + r;
-            if (r + 1 < RPT) load_row(win[(r + 3) & 3], y + 2);      // in flight during this row's arithmetic
+            const int y = y0 + gi * RPT + r;
+            if (r + 1 < RPT || gi + 1 < NG) load_row(win[(r + 3) & 3], y + 2);      // in flight during this row's arithmetic
             const float4 nz = *reinterpret_cast<const float4*>(p.noise + ((size_t)n * p.H + y) * p.W + x0);
             const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
             float v[4][4];
@@ -3679,9 +3684,22 @@ static int post_rpt(const PostParams& p) {
 }
 
 // workgroups per sample of the form launch_post picks
+// row groups per thread of post_rows_kernel<4> (GSA_POST_NG; default 1).  Measured, FFHQ batch 8, ms per launch at 1024 / 512 / 256 /
+// 128 px, kernels serialized: 1 group 0.274 / 0.133 / 0.061 / 0.031; 2: 0.260 / 0.127 / 0.058 / 0.030; 4: 0.257 / 0.117 / 0.058 / 0.032;
+// 8: 0.253 / 0.107 / 0.077 / 0.046 -- the best choice per size saves 0.04 ms of serialized kernel time per step, but the STEP (decoder
+// running beside the synthesis) was 0-1 % slower with it in four of four same-box comparisons (1257-1265 vs 1254-1256 pairs/s): fewer,
+// longer-lived workgroups leave the concurrent stream less room.  Not adopted.
+static int post_row_groups(const PostParams& p) {
+    static const int forced = getenv("GSA_POST_NG") ? atoi(getenv("GSA_POST_NG")) : -1;
+    if (post_rpt(p) != 4) return 1;
+    int ng = forced > 0 ? forced : 1;
+    while (ng > 1 && p.H % (4 * ng)) ng >>= 1;
+    return ng;
+}
+
 static int post_blocks(const PostParams& p) {
     const int rpt = post_rpt(p);
-    return rpt == 1 ? post_prow(p.H, p.W, p.C) : ((p.H / rpt) * (p.W / 4) * (p.C / 4) + 255) / 256;
+    return rpt == 1 ? post_prow(p.H, p.W, p.C) : ((p.H / (rpt * post_row_groups(p))) * (p.W / 4) * (p.C / 4) + 255) / 256;
 }
 
 int post_rows_used(const PostParams& p) {
@@ -3694,6 +3712,7 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
     PostParams q = p;
     const int rpt = post_rpt(p);
     q.prow = post_rows_used(p);
+    q.row_groups = post_row_groups(p);
     dim3 grid(post_blocks(p), n);
     const size_t lds = sizeof(unsigned long long) * 2 * p.C;
 #define GSA_POST(BF) \
