@@ -276,8 +276,8 @@ class TimedLoop:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (default 50: a third of a second of GPU time at FFHQ batch 8)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gan", default="ffhq", choices=("ffhq", "cars", "bedrooms"))
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU per step")
     ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"),
