@@ -19,7 +19,7 @@ API_SYMBOLS = (
     "generator_commit", "decoder_init", "decoder_set_param", "decoder_commit", "reserve",
     "generator_forward", "decoder_forward", "generate", "set_overlap", "set_precision", "segmentation_eval", "fill_inputs",
     "profile_enable", "profile_collect",
-    "profile_entry", "profile_reset", "version", "check",
+    "profile_entry", "profile_reset", "version", "check", "status_snapshot", "debug_inject",
 )
 
 
@@ -85,6 +85,8 @@ class Api:
             "profile_reset": (c.c_int, [vp]),
             "version": (c.c_char_p, []),
             "check": (c.c_int, [vp]),
+            "status_snapshot": (c.c_int, [vp, vp, vp]),
+            "debug_inject": (c.c_int, [vp, i32, i32]),
         }
         for name, (res, args) in sig.items():
             try:
@@ -141,6 +143,9 @@ class Context:
 
     def _check(self, rc, what):
         if rc < 0:
+            # any failing call ends the graph epoch: a pass that died half way leaves statistic rows that only the next EAGER
+            # pass re-zeroes (gsa_api.cpp run_generator), and a failed commit / reserve leaves nothing a captured graph may use
+            self.graph_epoch += 1
             raise GsaError("%s failed (%d): %s" % (what, rc, self._msg(self._h)))
         return rc
 
@@ -148,6 +153,14 @@ class Context:
         """gsa_check: synchronise the device and raise GsaError if a device-side check failed since the last clean one (the
         fused mapping network's exchange timed out; an instance-norm statistic left its fixed-point range)."""
         self._check(self.api.check(self._h), "check")
+
+    def status_snapshot(self, stream, host_ptr):
+        """gsa_status_snapshot: enqueue the 8-byte copy of the two sticky words to pinned host memory (no synchronisation)."""
+        self._check(self.api.status_snapshot(self._h, stream, host_ptr), "status_snapshot")
+
+    def debug_inject(self, kind, arg=0):
+        """gsa_debug_inject (tests only)."""
+        self._check(self.api.debug_inject(self._h, int(kind), int(arg)), "debug_inject")
 
     def _after_step(self):
         # ONE synchronising check per context, after its first step: a violated co-residency assumption or out-of-range
@@ -194,6 +207,7 @@ class Context:
 
     def generator_load(self, params):
         ignored = self._set_params(self.api.generator_set_param, params, "generator_set_param")
+        self.graph_epoch += 1       # the commit frees and re-uploads the weight panels a captured graph bakes in
         self._check(self.api.generator_commit(self._h), "generator_commit")
         return ignored
 
@@ -209,6 +223,7 @@ class Context:
 
     def decoder_load(self, params):
         self._set_params(self.api.decoder_set_param, params, "decoder_set_param")
+        self.graph_epoch += 1
         self._check(self.api.decoder_commit(self._h), "decoder_commit")
 
     def reserve(self, max_batch):

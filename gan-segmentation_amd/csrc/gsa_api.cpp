@@ -124,8 +124,9 @@ struct gsa_ctx {
     int prio = 0;                 // GSA_PRIO experiment switch
     int dbg = 0;                  // GSA_DBG, read once at gsa_create (only the diagnostic build looks at it)
     int side_levels = -1;         // decoder levels 0..side_levels-1 go to the side stream; -1 = by batch size (GSA_SIDE_LEVELS)
-    int fault = 0;                // GSA_FAULT (tests only), read at gsa_create: 1 = the fused mapping network is launched one workgroup short;
-                                  // 2 = the first generator pass returns an error between a statistics producer and its finalize
+    int fault = 0;                // gsa_debug_inject (tests only; never armed by the environment): 1 = the fused mapping network is launched one
+                                  // workgroup short; 2 = the next generator pass returns an error between a statistics producer and its finalize
+    int fault_range_after = -1;   // gsa_debug_inject kind 3: passes left until the statistics-range word is set on the pass's stream (-1 = off)
     size_t partials_bytes = 0, stat_acc_bytes = 0, ticket_bytes = 0;
     bool stats_dirty = false;     // a generator pass failed between a statistics producer and its finalize: the rows are re-zeroed by the next pass
 
@@ -520,7 +521,6 @@ int gsa_create(int device, gsa_ctx** out) {
     if (const char* v = getenv("GSA_SIDE_LEVELS")) c->side_levels = atoi(v);
     if (const char* v = getenv("GSA_DBG")) c->dbg = atoi(v);
     if (const char* v = getenv("GSA_PRIO")) c->prio = atoi(v);
-    if (const char* v = getenv("GSA_FAULT")) c->fault = atoi(v);
     *out = c;
     return GSA_OK;
 }
@@ -845,6 +845,24 @@ int gsa_check(gsa_ctx* c) {
     return read_device_status(c);
 }
 
+int gsa_status_snapshot(gsa_ctx* c, void* stream, uint32_t* host_words) {
+    if (!c || !host_words) return fail(c, GSA_ERR_INVALID, "gsa_status_snapshot: null argument");
+    if (!c->map_ctl) return fail(c, GSA_ERR_STATE, "gsa_status_snapshot before the first generator step (no workspace yet)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(host_words, c->map_ctl, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return GSA_OK;
+}
+
+int gsa_debug_inject(gsa_ctx* c, int32_t kind, int32_t arg) {
+    if (!c) return GSA_ERR_INVALID;
+    switch (kind) {
+    case 0: c->fault = 0; c->fault_range_after = -1; return GSA_OK;
+    case 1: case 2: c->fault = kind; return GSA_OK;
+    case 3: if (arg < 0) return fail(c, GSA_ERR_INVALID, "gsa_debug_inject(3): arg < 0"); c->fault_range_after = arg; return GSA_OK;
+    default: return fail(c, GSA_ERR_INVALID, "gsa_debug_inject: unknown kind %d", kind);
+    }
+}
+
 int gsa_reserve(gsa_ctx* c, int32_t max_batch) {
     if (!c) return GSA_ERR_INVALID;
     if (max_batch < 1) return fail(c, GSA_ERR_INVALID, "max_batch must be >= 1");
@@ -937,6 +955,10 @@ static int run_generator(gsa_ctx* c, hipStream_t s, int n, const float* z, const
     c->stats_dirty = true;
     const int rc = run_generator_pass(c, s, n, z, noise, rgb, img, feats, record_levels);
     if (rc == GSA_OK) c->stats_dirty = false;
+    if (rc == GSA_OK && c->fault_range_after >= 0 && c->fault_range_after-- == 0) {
+        // test hook: from this pass on the statistics-range word reads as if an instance norm had overflowed (it is sticky)
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->map_ctl, 1, 1, s));
+    }
     return rc;
 }
 
@@ -1018,7 +1040,7 @@ static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, 
             }
             if (c->fault == 2 && l == 1 && k == 1) {      // fault injection (tests): ONE pass dies between a producer and its finalize
                 c->fault = 0;
-                return fail(c, GSA_ERR_HIP, "injected fault (GSA_FAULT=2) between a statistics producer and its finalize");
+                return fail(c, GSA_ERR_HIP, "injected fault (gsa_debug_inject 2) between a statistics producer and its finalize");
             }
             FinalizeParams fp{};
             fp.partials = c->partials; fp.prow = prow; fp.HW = R * R; fp.C = C; fp.acc = c->stat_acc; fp.tickets = c->stat_tickets;

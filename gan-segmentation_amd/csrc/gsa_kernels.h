@@ -14,7 +14,10 @@ struct Aff { float mean, A, B, pad; };
 struct StatPart { unsigned long long s1, s2; };
 
 constexpr double kStatScale1 = 268435456.0;  // 2^28: quad sums
-constexpr double kStatScale2 = 1048576.0;    // 2^20: quad sums of squares
+// quad sums of squares: 2^S2 with S2 = clamp(40 - ceil(log2(H*W)), 20, 26), a static function of the plane size (round 4):
+// 20 at 1024^2 -- where the 64-bit sum of a plane holds rms(x) < 2.9e3 -- 22 / 24 at 512^2 / 256^2, 26 from 128^2 down.
+// Small planes have few quads to average the rounding of rint(q * 2^S2) over, and E[x^2] - mean^2 must survive the cancellation
+// when a plane's values sit on a bias far above their spread (device function stat_scale2 in gsa_kernels.hip; oracle: stat_scale2)
 
 enum Epilogue { EPI_RAW = 0, EPI_SYNTH = 1, EPI_DEC = 2 };
 

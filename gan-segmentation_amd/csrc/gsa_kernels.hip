@@ -86,6 +86,26 @@ __device__ __forceinline__ unsigned long long to_fixed(float v, double scale) {
     return (unsigned long long)__double_as_longlong(t) - (unsigned long long)__double_as_longlong(magic);
 }
 
+// Fixed-point sums of squares (round 4; gsa_kernels.h): the unit is 2^-S2 with S2 = clamp(40 - ceil(log2(H*W)), 20, 26), a static
+// function of the plane size -- fine enough on small planes that E[x^2] - mean^2 survives the cancellation when a plane's values
+// sit on a bias far above their spread, coarse enough at 1024^2 that the 64-bit sum holds rms(x) < 2.9e3.  A quad whose sum of
+// squares would not fit the 1.5*2^52 conversion at that unit (q >= 2^(50-S2)) is rounded at 2^-20 instead and shifted into the
+// unit: every term stays an integer multiple of 2^-S2 and a pure function of q, so the sum is order-independent as before, and the
+// per-value range stays |x| < 2.3e4 at every plane size.  S2 is wave-uniform (scalar registers).
+__device__ __forceinline__ int stat_s2(int HW) {
+    const int s2 = 40 - (HW > 1 ? 32 - __builtin_clz((unsigned)HW - 1u) : 0);
+    return s2 < 20 ? 20 : (s2 > 26 ? 26 : s2);
+}
+__device__ __forceinline__ double stat_scale2(int HW) { return __hiloint2double((1023 + stat_s2(HW)) << 20, 0); }
+__device__ __forceinline__ unsigned long long to_fixed_sq(float q, int s2) {
+    // pre-scaling a big q by the exact power of two 2^-(S2-20) and shifting the integer back IS rounding it at 2^-20; the
+    // conversion itself keeps its wave-uniform scale (one scalar register pair), only the mask and two selects are per lane
+    const bool big = q >= __int_as_float((127 + 50 - s2) << 23);
+    const float qs = big ? q * __int_as_float((127 + 20 - s2) << 23) : q;
+    const unsigned long long k = to_fixed(qs, __hiloint2double((1023 + s2) << 20, 0));
+    return k << (big ? s2 - 20 : 0);
+}
+
 // value of another lane of the same aligned quad (DPP quad_perm, no LDS traffic)
 template <int CTRL>
 __device__ __forceinline__ float dpp_quad(float v) {
@@ -610,7 +630,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
                         const float s = (v[0] + v[1]) + (v[2] + v[3]);
                         const float q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                         I1 += to_fixed(s, kStatScale1);
-                        I2 += to_fixed(q, kStatScale2);
+                        I2 += to_fixed_sq(q, stat_s2(p.H * p.W));
                     }
                     if (EPI == EPI_DEC) {
 #pragma unroll
@@ -1047,7 +1067,7 @@ __global__ __launch_bounds__(256 * PS) void conv3x3_ksplit(ConvParams p) {
         }
         const float sq = (v[0] + v[1]) + (v[2] + v[3]);
         const float qq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        unsigned long long I1 = to_fixed(sq, kStatScale1), I2 = to_fixed(qq, kStatScale2);
+        unsigned long long I1 = to_fixed(sq, kStatScale1), I2 = to_fixed_sq(qq, stat_s2(p.H * p.W));
         I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
         I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
         if (lane < 16) {
@@ -1410,7 +1430,7 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
                     const float sq = (v[0] + v[1]) + (v[2] + v[3]);
                     const float qq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                     I1 += to_fixed(sq, kStatScale1);
-                    I2 += to_fixed(qq, kStatScale2);
+                    I2 += to_fixed_sq(qq, stat_s2(p.H * p.W));
                 }
                 if (EPI == EPI_DEC) {
 #pragma unroll
@@ -2318,7 +2338,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
             const float s = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
             const float q = (v[0][j] * v[0][j] + v[1][j] * v[1][j]) + (v[2][j] * v[2][j] + v[3][j] * v[3][j]);
             atomicAdd(&sstat[c + j], to_fixed(s, kStatScale1));
-            atomicAdd(&sstat[p.C + c + j], to_fixed(q, kStatScale2));
+            atomicAdd(&sstat[p.C + c + j], to_fixed_sq(q, stat_s2(p.H * p.W)));
         }
     }
     __syncthreads();
@@ -2432,7 +2452,7 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
                 const float sq = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
                 const float qq = (v[0][j] * v[0][j] + v[1][j] * v[1][j]) + (v[2][j] * v[2][j] + v[3][j] * v[3][j]);
                 I1[j] += to_fixed(sq, kStatScale1);
-                I2[j] += to_fixed(qq, kStatScale2);
+                I2[j] += to_fixed_sq(qq, stat_s2(p.H * p.W));
             }
         }
 #pragma unroll
@@ -2517,7 +2537,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p, int row
         }
         const double inv_hw = 1.0 / (double)p.HW;   // HW is a power of two
         const double m = (double)(long long)I1 * (1.0 / kStatScale1) * inv_hw;
-        const double e2 = (double)(long long)I2 * (1.0 / kStatScale2) * inv_hw;
+        const double e2 = (double)(long long)I2 * (1.0 / stat_scale2(p.HW)) * inv_hw;
         double var = fma(-m, m, e2);
         // range check of the fixed-point sums (include/gsa.h): a sum within a factor 4 of the 64-bit wrap, or a variance that is
         // negative beyond rounding (what a wrapped sum of squares produces), sets the sticky word gsa_check reports

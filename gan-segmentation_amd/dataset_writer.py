@@ -82,6 +82,21 @@ def write_encoded_pair(dst_dir, index, jpeg_parts, img, png_stream, mask, H, W, 
         _write_mask(dst_dir, index, mask)
 
 
+class DeviceCheckFailed(RuntimeError):
+    """A batch's status snapshot (``ImageGenerator.snapshot_status``) was non-zero: ``first_index`` is the global index of
+    the first sample whose files were withheld; every file below it was checked clean."""
+
+    def __init__(self, first_index, words):
+        self.first_index, self.words = int(first_index), tuple(int(w) for w in words)
+        what = []
+        if self.words[0]:
+            what.append("an instance-norm statistic left the range of its 64-bit fixed-point sum")
+        if self.words[1]:
+            what.append("the fused mapping network timed out waiting for a partner workgroup")
+        super().__init__("device-side check failed in the batch starting at global sample index %d (%s): the files from "
+                         "index %d on were not written, everything below is valid" % (self.first_index, "; ".join(what), self.first_index))
+
+
 class DatasetWriter:
     """``submit(img, mask, first_index)`` returns immediately; ``close()`` waits for every file."""
 
@@ -104,17 +119,23 @@ class DatasetWriter:
         self._errors = []
         self._lock = threading.Lock()
         self._copy_stream = None
+        self._status = {}                    # first_index -> pinned status slots of that batch (or None)
+        self._halted = False                 # a batch failed its device-side check: nothing from there on is written
         self._dispatcher = threading.Thread(target=self._dispatch, daemon=True)
         self._dispatcher.start()
         self.written = 0
         self.submitted = 0
 
     # -- producer side ----------------------------------------------------------------------
-    def submit(self, img, mask, first_index):
-        """img (N,R,R,3) u8, mask (N,R,R) u8: torch CUDA tensors (copied asynchronously) or numpy."""
+    def submit(self, img, mask, first_index, status=None):
+        """img (N,R,R,3) u8, mask (N,R,R) u8: torch CUDA tensors (copied asynchronously) or numpy.
+        ``status``: the pinned snapshot slots ``ImageGenerator.snapshot_status()`` returned for THIS batch (enqueued on the
+        producing stream before this call); the dispatcher reads them when the batch's copies have completed and withholds
+        the batch's files -- and every later one -- if a device-side check had failed by then (``DeviceCheckFailed``)."""
         if self._errors:
             raise self._errors[0]
         self.submitted += int(img.shape[0])
+        self._status[first_index] = status
         if isinstance(img, np.ndarray):
             self._pending.put((None, None, np.ascontiguousarray(img), np.ascontiguousarray(mask), first_index))
             return
@@ -231,6 +252,16 @@ class DatasetWriter:
             try:
                 if ev is not None:
                     ev.synchronize()
+                # the copy stream waited for the producing stream, so the 8-byte status copy enqueued there before submit()
+                # has landed: look at it BEFORE any file of this batch exists
+                status = self._status.pop(first, None)
+                if self._halted:
+                    raise DeviceCheckFailed(first, (1, 0))
+                if status is not None:
+                    words = [int(v) for t in status for v in t.tolist()]
+                    if any(words):
+                        self._halted = True
+                        raise DeviceCheckFailed(first, (any(words[0::2]), any(words[1::2])))
                 if isinstance(img, dict):         # (partly) compressed on the GPU
                     p = img
                     scans = self._fetch_encoded(slot, "jpeg", *p["jpeg"][1:]) if "jpeg" in p else None

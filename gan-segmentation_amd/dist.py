@@ -24,15 +24,13 @@ def shard_bounds(total, world_size, rank):
 def env_ranks():
     """(rank, world, local_rank) from the torchrun environment WITHOUT creating a process group: all a path
     needs whose ranks never talk to each other (``main.py generate`` writing files: ``shard_bounds`` only)."""
-    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
-            int(os.environ.get("LOCAL_RANK", "0")))
+    return (int(os.environ.get("RANK") or 0), int(os.environ.get("WORLD_SIZE") or 1),
+            int(os.environ.get("LOCAL_RANK") or 0))
 
 
 def init_from_env(backend=None):
     """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun)."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = env_ranks()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -21,6 +21,9 @@ from .networks_seg import Decoder
 from .networks_stylegan import Generator
 
 
+_GRAPH_CAPTURES_MAX = 16
+
+
 class ImageGenerator:
     def __init__(self, gpu_ids, gan_dir, gan="ffhq", batch_size=4, return_latents=False, seed=0, precision="fp32"):
         max_res_log2_dict = _weights.GAN_MAX_RES_LOG2
@@ -197,7 +200,9 @@ class ImageGenerator:
             # A small step is a latency chain of ~100 launches of 10-60 us: when the very same call comes again (same batch,
             # same input and output addresses -- a steady loop over preallocated or recycled tensors) often enough it is replayed
             # from a captured hipGraph (+2-3 % at batch <= 2 and in bf16 mode; nothing at batch 8, where it stays eager).  The key holds
-            # every pointer the graph bakes in, so a replay always reads the current inputs and writes the current outputs.
+            # every pointer the graph bakes in, so a replay always reads the current inputs and writes the current outputs; the
+            # epoch changes whenever the context's workspace, weights or stream structure change AND whenever a call of the
+            # context failed (a failed pass leaves statistic rows the next EAGER pass re-zeroes -- a replay would not).
             key = (n, z.data_ptr(), tuple(nptrs), img.data_ptr(), mask.data_ptr(), torch.cuda.current_stream(dev).cuda_stream,
                    model.ctx.graph_epoch)
             cache = model.__dict__.setdefault("_graphs", {})
@@ -207,29 +212,87 @@ class ImageGenerator:
                 return img, mask
             seen = model.__dict__.setdefault("_graph_seen", {})
             seen[key] = seen.get(key, 0) + 1
-            # Capturing costs several milliseconds (about as much as five steps): a call is captured only after it has come 32 times
-            # -- a steady loop (main.py generate: thousands of steps), never a short benchmark or a one-off call
-            if seen[key] >= 32 and model.ctx._checked_first_step:
+            # Capturing costs about as much as a few steps: a call is captured only after it has come `graph_after` (32) times
+            # -- a steady loop (main.py generate: thousands of steps), never a one-off call -- and a model captures at most
+            # `_GRAPH_CAPTURES_MAX` times in its life (a caller whose addresses keep changing stays eager instead of re-capturing)
+            if (seen[key] >= self.graph_after and model.ctx._checked_first_step
+                    and model.__dict__.get("_graph_captures", 0) < _GRAPH_CAPTURES_MAX):
+                model.__dict__["_graph_captures"] = model.__dict__.get("_graph_captures", 0) + 1
                 if len(cache) >= 8:
                     cache.pop(next(iter(cache)))
                 if len(seen) > 64:
                     seen.clear()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    model.ctx.generate(current_stream_ptr(dev), n, z.data_ptr(), nptrs, img.data_ptr(), mask.data_ptr())
+                graph = self._capture(model, dev, n, z, nptrs, img, mask)
                 graph.replay()
                 cache[key] = graph
                 return img, mask
         model.ctx.generate(current_stream_ptr(dev), n, z.data_ptr(), nptrs, img.data_ptr(), mask.data_ptr())
         return img, mask
 
+    @staticmethod
+    def _capture(model, dev, n, z, nptrs, img, mask):
+        """Capture one fused step into a hipGraph on a capture stream of our own: ``CUDAGraph.capture_begin/capture_end``
+        directly -- not the ``torch.cuda.graph`` context manager, whose device-wide synchronize, ``gc.collect`` and
+        ``empty_cache()`` would stall the caller's steady loop and could move its recycled tensors to new addresses."""
+        cur = torch.cuda.current_stream(dev)
+        side = model.__dict__.get("_capture_stream")
+        if side is None:
+            side = model.__dict__["_capture_stream"] = torch.cuda.Stream(device=dev)
+        graph = torch.cuda.CUDAGraph()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            graph.capture_begin(capture_error_mode="thread_local")
+            try:
+                model.ctx.generate(side.cuda_stream, n, z.data_ptr(), nptrs, img.data_ptr(), mask.data_ptr())
+            finally:
+                graph.capture_end()
+        cur.wait_stream(side)
+        return graph
+
     def _graph_wanted(self, model, n):
-        """hipGraph replay of the fused step: GSA_GRAPH=0 never, 1 always, default = where it measured faster (bf16 mode, fp32
-        batches of at most 2); never while per-launch profiling events are on."""
-        mode = os.environ.get("GSA_GRAPH", "")
+        """hipGraph replay of the fused step: mode "0" never, "1" always, default = where it measured faster (bf16 mode, fp32
+        batches of at most 2); never while per-launch profiling events are on.  ``self.graph_mode`` / ``self.graph_after``
+        override the environment's GSA_GRAPH / GSA_GRAPH_AFTER."""
+        mode = self.graph_mode if self.graph_mode is not None else os.environ.get("GSA_GRAPH", "")
         if mode == "0" or model.ctx.profiling or len(self._gens) != 1:
             return False
         return mode == "1" or self.precision == "bf16" or n <= 2
+
+    graph_mode = None       # None: GSA_GRAPH decides; "0" / "1"
+
+    @property
+    def graph_after(self):
+        v = self.__dict__.get("_graph_after")
+        return v if v is not None else int(os.environ.get("GSA_GRAPH_AFTER", "32"))
+
+    @graph_after.setter
+    def graph_after(self, v):
+        self.__dict__["_graph_after"] = v
+
+    def graphs_captured(self):
+        """Number of hipGraphs the replicas hold (bench.py reports whether its timed loop replayed one)."""
+        return sum(len(g._model.__dict__.get("_graphs", {})) for g in self._gens)
+
+    def snapshot_status(self):
+        """In-flight form of the device-side checks (include/gsa.h gsa_status_snapshot): enqueues, behind the kernels of the
+        batch just submitted on every replica's current stream, an 8-byte copy of the context's two sticky words into a pinned
+        host slot and returns those slots ([2] int32 tensors, one per replica) WITHOUT synchronising.  The reader -- the
+        ``DatasetWriter`` dispatcher, before it releases that batch's files -- looks at them once an event recorded behind this
+        call has completed; non-zero = that batch (or an earlier one since the last clean look) must be discarded."""
+        ring = self.__dict__.get("_status_ring")
+        if ring is None:
+            ring = self.__dict__["_status_ring"] = [torch.zeros((32, 2), dtype=torch.int32).pin_memory() for _ in self._gens]
+            self.__dict__["_status_next"] = 0
+        k = self.__dict__["_status_next"]
+        self.__dict__["_status_next"] = (k + 1) % 32
+        views = []
+        for g, slots in zip(self._gens, ring):
+            dev = g._model.device
+            view = slots[k]
+            with torch.cuda.device(dev):
+                g._model.ctx.status_snapshot(current_stream_ptr(dev), view.data_ptr())
+            views.append(view)
+        return views
 
     def _collect(self, parts, n, out):
         """Per-device results -> one (img, mask) pair on the first device, in sample order."""

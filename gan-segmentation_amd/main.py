@@ -51,7 +51,7 @@ def shard_batches(n_generate, batch, world, rank):
 def generate(cfg, limit=None, workers=None):
     import torch
     from . import dist as gdist
-    from .dataset_writer import DatasetWriter
+    from .dataset_writer import DatasetWriter, DeviceCheckFailed
     from .image_generator import ImageGenerator
     from .seg_solver import SegSolver
     from .weights import GAN_MAX_RES_LOG2
@@ -81,11 +81,17 @@ def generate(cfg, limit=None, workers=None):
     # additive keys JPEG_ON_GPU / PNG_ON_GPU (default on): the files are compressed by the HIP kernels behind
     # include/gsa_jpeg.h and include/gsa_png.h; the host threads only frame and write them
     on_gpu = bool(cfg.get("JPEG_ON_GPU", True))
-    with DatasetWriter(dst_dir, workers=workers, gpu_jpeg=on_gpu, gpu_png=bool(cfg.get("PNG_ON_GPU", on_gpu))) as writer:
-        for index, bs in shard_batches(n_generate, batch, world, rank):
-            # latents and noise keyed on the global sample index: the files are the same for any number of ranks
-            img, mask = netG.generate_indexed(index, bs, seed=seed)
-            writer.submit(img, mask, index)
+    try:
+        with DatasetWriter(dst_dir, workers=workers, gpu_jpeg=on_gpu, gpu_png=bool(cfg.get("PNG_ON_GPU", on_gpu))) as writer:
+            for index, bs in shard_batches(n_generate, batch, world, rank):
+                # latents and noise keyed on the global sample index: the files are the same for any number of ranks
+                img, mask = netG.generate_indexed(index, bs, seed=seed)
+                # the device-side checks travel with the batch: 8 bytes copied behind its kernels, read by the writer before it
+                # releases the batch's files -- a run of 10 000 samples stops at the first bad batch instead of reporting at close()
+                writer.submit(img, mask, index, status=netG.snapshot_status())
+    except DeviceCheckFailed as e:
+        print("generate: %s" % e, file=sys.stderr)
+        return -2
     torch.cuda.synchronize()
     return 0
 

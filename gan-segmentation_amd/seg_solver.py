@@ -138,10 +138,23 @@ class SegSolver:
             if epoch_end_callback is not None:
                 epoch_end_callback()
         self.load_parameters(tr.state_dict())
+        # rank 0 writes the checkpoint; the other ranks must not go on to load() it before it is complete -- and must not wait
+        # for ever if the write fails (disk full, bad path): the ranks exchange a success flag in place of a plain barrier and
+        # every rank raises
+        save_error = None
         if rank == 0:
-            self.save()
+            try:
+                self.save()
+            except Exception as e:       # noqa: BLE001 -- re-raised below, on every rank
+                save_error = e
         if world > 1:
-            tdist.barrier()      # no rank may go on to load() the checkpoint rank 0 is still writing
+            flag = torch.tensor([0 if save_error is None else 1], dtype=torch.int32,
+                                device=self.net._model.device if tdist.get_backend() == "nccl" else "cpu")
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MAX)
+            if int(flag.item()) and save_error is None:
+                raise RuntimeError("fit: rank 0 could not write the checkpoint (see its error)")
+        if save_error is not None:
+            raise save_error
         return history
 
     # -- evaluation ------------------------------------------------------

@@ -500,14 +500,35 @@ static inline uint64_t to_fixed(float v, double scale) {
     return bits - mbits;
 }
 
-/* fixed-point scales of the statistics: quad sum at 2^-28, quad sum of squares at 2^-20 */
+/* fixed-point scales of the statistics: quad sum at 2^-28; quad sum of squares in units of 2^-S2 with S2 a static function of the
+ * plane size alone (round 4): S2 = clamp(40 - ceil(log2(H*W)), 20, 26) -- 20 at 1024^2 (the 64-bit sum of a plane then holds
+ * rms(x) < 2.9e3 whatever the size), 22 / 24 at 512^2 / 256^2, 26 from 128^2 down.  A small plane has few quads to average the
+ * rounding of rint(q * 2^S2) over, and a plane whose values sit on a bias far above their spread needs E[x^2] - mean^2 to survive
+ * the cancellation: at 2^-20 a 4x4 plane with values 0.1 +- 0.003 had its variance off by 10 %.  A quad with q >= 2^(50-S2) does
+ * not fit the 1.5*2^52 conversion at that unit: it is rounded at 2^-20 and shifted into the unit (still an integer multiple of
+ * 2^-S2 and a pure function of q: the sum stays order-independent, the per-value range stays |x| < 2.3e4). */
 #define STAT_SCALE1 268435456.0
-#define STAT_SCALE2 1048576.0
+static int stat_s2(int HW) {
+    int lg = 0;
+    while ((1 << lg) < HW) ++lg;
+    int s2 = 40 - lg;
+    if (s2 < 20) s2 = 20;
+    if (s2 > 26) s2 = 26;
+    if (getenv("GSAO_STAT_S2")) s2 = atoi(getenv("GSAO_STAT_S2"));   /* experiment switch (tests/test_oracle.py) */
+    return s2;
+}
+static double stat_scale2(int HW) { return (double)(1ull << stat_s2(HW)); }
+static inline uint64_t to_fixed_sq(float q, int s2) {
+    const int big = q >= (float)(1ull << (50 - s2));
+    const uint64_t k = to_fixed(q, (double)(1ull << (big ? 20 : s2)));
+    return k << (big ? s2 - 20 : 0);
+}
 
 typedef struct { float mean, A, B; } affine3;
 
 /* per-(n,c) fixed-point statistics of an NHWC plane set x[H][W][C] */
 static void plane_stats(const float* x, int H, int W, int C, uint64_t* I1, uint64_t* I2) {
+    const int s2 = stat_s2(H * W);
     for (int c = 0; c < C; ++c) I1[c] = I2[c] = 0;
     for (int y = 0; y < H; ++y)
         for (int x0 = 0; x0 < W; x0 += 4) {
@@ -517,7 +538,7 @@ static void plane_stats(const float* x, int H, int W, int C, uint64_t* I1, uint6
                 float s = (v0 + v1) + (v2 + v3);
                 float q = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
                 I1[c] += to_fixed(s, STAT_SCALE1);
-                I2[c] += to_fixed(q, STAT_SCALE2);
+                I2[c] += to_fixed_sq(q, s2);
             }
         }
 }
@@ -528,6 +549,7 @@ static void plane_stats(const float* x, int H, int W, int C, uint64_t* I1, uint6
 static void finalize(const uint64_t* I1, const uint64_t* I2, int HW, int C, const float* style /*2C*/,
                      const float* gamma, const float* beta, affine3* out) {
     const double inv_hw = 1.0 / (double)HW; /* HW is a power of two: exact */
+    const double STAT_SCALE2 = stat_scale2(HW);
     for (int c = 0; c < C; ++c) {
         double m = (double)(int64_t)I1[c] * (1.0 / STAT_SCALE1) * inv_hw;
         double e2 = (double)(int64_t)I2[c] * (1.0 / STAT_SCALE2) * inv_hw;

@@ -1,8 +1,10 @@
 """Generates tests/golden/f64_yardstick.npz: the reference-order restatement (oracle/ref_semantic.py) evaluated in FLOAT64 for
-bedrooms 256^2 and cars 512^2 at full size (tests.common.gan_setup inputs, batch 1), stored as strided samples of rgb and
-logits (< 1 MB), together with the error of the SAME restatement in fp32 at those points.
+bedrooms 256^2, cars 512^2 and ffhq 1024^2 (the headline configuration; added in round 4) at full size (tests.common.gan_setup
+inputs, batch 1), stored as strided samples of rgb and logits (< 1 MB), together with the error of the SAME restatement in fp32
+at those points.
 
-    python tests/golden/make_f64_yardstick.py          (a few minutes of CPU)
+    python tests/golden/make_f64_yardstick.py [gan ...]     (a few minutes of CPU; named GANs are recomputed and merged
+                                                             into the existing file, no argument = all three)
 
 It gives the north-star tolerance ("<= 1e-3 vs the reference mxnet CPU path") a yardstick: the fp32 reference order is itself
 max|sem32 - f64| away from the exact result; tests/test_gpu_parity.py::test_accuracy_against_the_fp64_yardstick asserts that the
@@ -20,12 +22,18 @@ sys.path.insert(0, ROOT)
 from oracle import ref_semantic as S      # noqa: E402
 from tests.common import gan_setup         # noqa: E402
 
-STRIDE = {"bedrooms": 4, "cars": 8}
+STRIDE = {"bedrooms": 4, "cars": 8, "ffhq": 16}
 
 
 def main():
+    path = os.path.join(ROOT, "tests", "golden", "f64_yardstick.npz")
     out = {}
-    for gan, st in STRIDE.items():
+    which = sys.argv[1:] or list(STRIDE)
+    if os.path.exists(path) and sys.argv[1:]:
+        with np.load(path) as g:
+            out = {k: g[k] for k in g.files}
+    for gan in which:
+        st = STRIDE[gan]
         gcfg, gp, dcfg, dp, z, noise = gan_setup(gan, 1)
         _i, _m, rgb64, _f, log64 = S.generate(gcfg, gp, dcfg, dp, z, noise, dtype=torch.float64)
         _i, _m, rgb32, _f, log32 = S.generate(gcfg, gp, dcfg, dp, z, noise)
@@ -38,7 +46,7 @@ def main():
         out[gan + "_sem32_err_logits"] = np.float64(np.abs(l32 - l64).max())
         print(gan, "stride", st, "rgb range", float(np.abs(r64).max()), "fp32 reference-order error: rgb %.3g logits %.3g"
               % (out[gan + "_sem32_err_rgb"], out[gan + "_sem32_err_logits"]), flush=True)
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "f64_yardstick.npz"), **out)
+    np.savez_compressed(path, **out)
 
 
 if __name__ == "__main__":

@@ -465,6 +465,65 @@ def test_bench_timed_loop_world_size_2_on_gloo(tmp_path):
         assert tag in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def _bench_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    import json
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's N=1 command): the parent starts two
+    fresh rank processes, the real main() runs on gloo with the stub producer, ONE line comes back and it proves its ranks
+    (reference image_generator.py:95-114: the batch split over the device list + gather)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-producer", "--steps", "3",
+                          "--warmup", "2", "--batch", "2"], capture_output=True, text=True, timeout=300, env=_bench_env())
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = _one_json_line(out.stdout)
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and len(line["devices"]) == 2
+    assert line["config"]["gather"] == "overlapped" and line["config"]["backend"] == "gloo"
+    assert line["launcher"].startswith("self-launched") and line["data"] == "stub"
+    assert line["gathered_matches_producers"] is True and line["steps"] == 3 and line["config"]["global_batch"] == 4
+
+
+def test_bench_under_torchrun_is_unchanged_and_a_dead_rank_fails_the_run():
+    """Under torch.distributed.run (the documented N>1 command) nothing is re-launched; and without a launcher a rank that
+    exits non-zero (here: no HIP device for the real producer) makes the parent exit non-zero instead of hanging."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-producer",
+                          "--steps", "2", "--warmup", "1", "--batch", "2"], capture_output=True, text=True, timeout=300, env=_bench_env())
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = _one_json_line(out.stdout)
+    assert line["ranks"] == 2 and line["launcher"].startswith("external") and line["config"]["gather"] == "overlapped"
+    import torch
+    if not torch.cuda.is_available():
+        bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                             capture_output=True, text=True, timeout=300, env=_bench_env())
+        assert bad.returncode != 0 and "{" not in bad.stdout, bad.stdout[-1000:]
+        assert "stopping the other ranks" in bad.stderr or "needs a HIP device" in bad.stderr
+
+
+def test_bench_roofline_fields_are_fractions():
+    """`roofline.frac` is what the pipe does: executed FLOP / time / peak for an MFMA-bound kernel, algorithmic bytes / time /
+    8 TB/s for an HBM-bound one -- never the reference-formulation throughput, which moved to algorithmic_*."""
+    import bench
+    wino = {"name": "k", "ms": 1.0495, "launches": 5, "flops": 5 * 14.6e9, "alg_flops": 5 * 32.86e9, "bytes": 5 * 103e6}
+    r = bench.roofline_of(wino, "fp32", None)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.43 < r["frac"] < 0.45 and r["achieved"] == r["executed_tflops"]
+    assert r["algorithmic_frac"] > 0.99 and r["traffic"] is None
+    blur = {"name": "post", "ms": 0.27, "launches": 1, "flops": 0.0, "alg_flops": 0.0, "bytes": 1.07e9}
+    r = bench.roofline_of(blur, "fp32", {"bytes_per_launch": 1.2e9, "source": "x.json"})
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0.45 < r["frac"] < 0.55 and r["traffic"] == 1.2e9
+    t_mfma, t_hbm = bench.roof_seconds([wino, blur], "fp32")
+    assert abs(t_mfma - 5 * 14.6e9 / 157.3e12) < 1e-9 and abs(t_hbm - 1.07e9 / 6.29e12) < 1e-9
+
+
 def test_generate_devices_single_process():
     """One process (the reference's way): the whole GAN_GPU_IDS list is used in-process, the batch is
     GAN_BATCH_SIZE_PER_GPU * len(GAN_GPU_IDS) (reference main.py:87-88); an empty list has no CPU fallback."""
