@@ -286,6 +286,130 @@ static float* pack_wino(const float* w, int O, int I, float std, int use_std, fl
     return out;
 }
 
+/* ---- Winograd F(4x4, 3x3) form (round 4) -------------------------------------------------------------------------
+ * Rule (static, by layer shape only): a layer that takes the Winograd form above AND has at least 64 input channels (the
+ * streamed-weight layers: synthesis conv_2 at 16^2-256^2, decoder cvt at 64^2-256^2) is evaluated per 4x4 OUTPUT tile from its
+ * 6x6 input patch: 36 products per 16 outputs instead of 64 (F(2x2,3x3)) or 144 (direct).  Lavin & Gray's matrices
+ *     B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+ *     G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+ *     A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+ * Canonical arithmetic (every fp32 op rounded; fmaf where written, every constant a power of two or 5):
+ *   weights    U = G g G^T in DOUBLE on the effective fp32 weights, rounded to fp32 once;
+ *   input      per 6-vector d (first down the columns of the patch, then along the rows of the result):
+ *                a = fmaf(-4, d2, d4), b = fmaf(-4, d1, d3), c = d4 - d2, e = d3 - d1,
+ *                t0 = fmaf(4, d0, fmaf(-5, d2, d4)), t1 = a + b, t2 = a - b, t3 = fmaf(2, e, c), t4 = fmaf(-2, e, c),
+ *                t5 = fmaf(4, d1, fmaf(-5, d3, d5));
+ *   products   M[f] = one fmaf chain over the input channels per frequency f = 6i+j (block order as everywhere);
+ *   output     per 6-vector m (first down the columns of M, then along the rows):
+ *                p = m1 + m2, q = m1 - m2, r = m3 + m4, s = m3 - m4,
+ *                y0 = (m0 + p) + r, y1 = fmaf(2, s, q), y2 = fmaf(4, r, p), y3 = fmaf(8, s, q) + m5. */
+#ifndef OC
+#define OC 16
+#endif
+static int g_wino43 = -1;
+static int use_wino43(int H, int W, int Cin, int Cout, int bf) {
+    if (g_wino43 < 0) { const char* e = getenv("GSAO_WINO43"); g_wino43 = e ? atoi(e) : 0;   /* off until the HIP kernel carries the same rule */ }
+    return g_wino43 && use_wino(H, W, Cout, 0, bf) && Cin >= 64;
+}
+
+/* conv OIHW (O,I,3,3) -> U packed [(cb*36 + f)*CB + c][O], f = 6*i + j */
+static float* pack_wino43(const float* w, int O, int I, float std, int use_std, float lr) {
+    static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    float* out = (float*)malloc(sizeof(float) * (size_t)O * I * 36);
+    for (int cb = 0; cb < I / CB; ++cb)
+        for (int ci = 0; ci < CB; ++ci)
+            for (int o = 0; o < O; ++o) {
+                const float* wk = w + ((size_t)o * I + cb * CB + ci) * 9;
+                double g[3][3], r[6][3];
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) g[a][b] = (double)eff(wk[a * 3 + b], std, use_std, lr);
+                for (int i = 0; i < 6; ++i)
+                    for (int b = 0; b < 3; ++b) r[i][b] = (G[i][0] * g[0][b] + G[i][1] * g[1][b]) + G[i][2] * g[2][b];
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j)
+                        out[(((size_t)cb * 36 + i * 6 + j) * CB + ci) * O + o] = (float)((r[i][0] * G[j][0] + r[i][1] * G[j][1]) + r[i][2] * G[j][2]);
+            }
+    return out;
+}
+
+static inline void wino43_in(const float d[6], float t[6]) {
+    const float a = fmaf(-4.0f, d[2], d[4]), b = fmaf(-4.0f, d[1], d[3]), c = d[4] - d[2], e = d[3] - d[1];
+    t[0] = fmaf(4.0f, d[0], fmaf(-5.0f, d[2], d[4]));
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = fmaf(2.0f, e, c);
+    t[4] = fmaf(-2.0f, e, c);
+    t[5] = fmaf(4.0f, d[1], fmaf(-5.0f, d[3], d[5]));
+}
+static inline void wino43_out(const float m[6], float y[4]) {
+    const float p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+    y[0] = (m[0] + p) + r;
+    y[1] = fmaf(2.0f, s, q);
+    y[2] = fmaf(4.0f, r, p);
+    y[3] = fmaf(8.0f, s, q) + m[5];
+}
+
+/* 3x3 conv, pad 1, NHWC, Winograd F(4x4,3x3) form.  in: [H][W][Cin] affine-applied; U from pack_wino43. */
+static void conv3x3_wino43(const float* in, int H, int W, int Cin, const float* U, int Cout, float* out) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int ty = 0; ty < H / 4; ++ty) {
+        float* V = (float*)malloc(sizeof(float) * 36 * (size_t)Cin);       /* [f][c] of the current tile */
+        for (int tx = 0; tx < W / 4; ++tx) {
+            for (int c = 0; c < Cin; ++c) {
+                float d[6][6], t[6][6], col[6], res[6];
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) {
+                        const int yy = 4 * ty - 1 + i, xx = 4 * tx - 1 + j;
+                        d[i][j] = (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0.0f : in[((size_t)yy * W + xx) * Cin + c];
+                    }
+                for (int j = 0; j < 6; ++j) {            /* down the columns: t = B^T d */
+                    for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+                    wino43_in(col, res);
+                    for (int i = 0; i < 6; ++i) t[i][j] = res[i];
+                }
+                for (int i = 0; i < 6; ++i) {            /* along the rows: V = t B */
+                    wino43_in(t[i], res);
+                    for (int j = 0; j < 6; ++j) V[(i * 6 + j) * Cin + c] = res[j];
+                }
+            }
+            for (int o0 = 0; o0 < Cout; o0 += OC) {
+                const int on = Cout - o0 < OC ? Cout - o0 : OC;
+                static _Thread_local float M[36][OC];
+                for (int f = 0; f < 36; ++f) {
+                    float acc[OC];
+                    for (int o = 0; o < OC; ++o) acc[o] = 0.0f;
+                    for (int cb = 0; cb < Cin / CB; ++cb)
+                        for (int kk = 0; kk < CB; ++kk) {
+                            const int ci = CPERM(kk);
+                            const float a = V[f * Cin + cb * CB + ci];
+                            const float* wrow = U + (((size_t)cb * 36 + f) * CB + ci) * Cout + o0;
+                            for (int o = 0; o < on; ++o) acc[o] = fmaf(a, wrow[o], acc[o]);
+                        }
+                    for (int o = 0; o < OC; ++o) M[f][o] = acc[o];
+                }
+                for (int o = 0; o < on; ++o) {
+                    float sr[4][6], col[6], res[4];
+                    for (int j = 0; j < 6; ++j) {        /* down the columns of M */
+                        for (int i = 0; i < 6; ++i) col[i] = M[i * 6 + j][o];
+                        wino43_out(col, res);
+                        for (int i = 0; i < 4; ++i) sr[i][j] = res[i];
+                    }
+                    for (int i = 0; i < 4; ++i) {        /* along the rows */
+                        wino43_out(sr[i], res);
+                        for (int j = 0; j < 4; ++j) out[((size_t)(4 * ty + i) * W + 4 * tx + j) * Cout + o0 + o] = res[j];
+                    }
+                }
+            }
+        }
+        free(V);
+    }
+}
+
+static float* pack_wino_any(const float* w, int O, int I, float std, int use_std, float lr, int R, int bf) {
+    return use_wino43(R, R, I, O, bf) ? pack_wino43(w, O, I, std, use_std, lr) : pack_wino(w, O, I, std, use_std, lr);
+}
+
 static float* copy_scaled(const float* w, int64_t n, float std, int use_std, float lr) {
     float* out = (float*)malloc(sizeof(float) * (size_t)n);
     for (int64_t i = 0; i < n; ++i) out[i] = eff(w[i], std, use_std, lr);
@@ -461,7 +585,7 @@ GSAO_API int gsao_generator_commit(gsao_ctx* c) {
         { int rc = get_std(c, t, pf, &std); if (rc) return rc; }
         snprintf(nm, sizeof nm, "%s_weight", pf); NEED(t, nm, (int64_t)C * C * 9, &w);
         B->w2 = pack_conv(w, C, C, 3, std, us, 1.0f);
-        B->w2u = pack_wino(w, C, C, std, us, 1.0f);
+        B->w2u = pack_wino_any(w, C, C, std, us, 1.0f, R, c->bf16);
         for (int k = 0; k < 2; ++k) {
             snprintf(nm, sizeof nm, "%d_noise_%d_scale_factors", R, k + 1); NEED(t, nm, C, &w); B->nscale[k] = copy_plain(w, C);
             snprintf(nm, sizeof nm, "%d_bias_%d_bias", R, k + 1); NEED(t, nm, C, &w); B->nbias[k] = copy_plain(w, C);
@@ -954,7 +1078,8 @@ GSAO_API int gsao_generator_forward(gsao_ctx* c, void* stream, int32_t n, const 
                         blur3x3(xc, R, R, C, B->blur, xa);
                     }
                 } else {
-                    if (use_wino(R, R, C, 0, c->bf16)) conv3x3_wino(xb, R, R, C, B->w2u, C, xa);
+                    if (use_wino43(R, R, C, C, c->bf16)) conv3x3_wino43(xb, R, R, C, B->w2u, C, xa);
+                    else if (use_wino(R, R, C, 0, c->bf16)) conv3x3_wino(xb, R, R, C, B->w2u, C, xa);
                     else conv3x3(xb, R, R, C, 0, B->w2, C, xa, c->bf16, 1);
                 }
                 noise_bias_act(xa, R, R, C, nz, B->nscale[k], B->nbias[k]);
@@ -1046,7 +1171,7 @@ GSAO_API int gsao_decoder_commit(gsao_ctx* c) {
         d->F = c->d_feat[i]; d->I = c->d_inch[i];
         snprintf(nm, sizeof nm, "cvt_block_%d.0.weight", i); NEED(t, nm, (int64_t)d->F * d->I * 9, &w);
         d->cvt_w = pack_conv(w, d->F, d->I, 3, 1.0f, 0, 1.0f);
-        d->cvt_u = pack_wino(w, d->F, d->I, 1.0f, 0, 1.0f);
+        d->cvt_u = pack_wino_any(w, d->F, d->I, 1.0f, 0, 1.0f, 4 << i, c->bf16);
         snprintf(nm, sizeof nm, "cvt_block_%d.0.bias", i); NEED(t, nm, d->F, &b); d->cvt_b = copy_plain(b, d->F);
         snprintf(pf, sizeof pf, "cvt_block_%d.1", i);
         { int rc = load_bn(c, pf, d->F, &d->cvt_s, &d->cvt_rm, &d->cvt_beta); if (rc) return rc; }
@@ -1063,7 +1188,7 @@ GSAO_API int gsao_decoder_commit(gsao_ctx* c) {
             { int rc = load_bn(c, nm, d->cs, &d->a_s, &d->a_rm, &d->a_beta); if (rc) return rc; }
             snprintf(nm, sizeof nm, "%s.%d.weight", pf, second); NEED(t, nm, (int64_t)d->cs * d->cs * 9, &w);
             d->b_w = pack_conv(w, d->cs, d->cs, 3, 1.0f, 0, 1.0f);
-            d->b_u = pack_wino(w, d->cs, d->cs, 1.0f, 0, 1.0f);
+            d->b_u = pack_wino_any(w, d->cs, d->cs, 1.0f, 0, 1.0f, 8 << i, c->bf16);
             snprintf(nm, sizeof nm, "%s.%d.bias", pf, second); NEED(t, nm, d->cs, &b); d->b_b = copy_plain(b, d->cs);
             snprintf(nm, sizeof nm, "%s.%d", pf, second + 1);
             { int rc = load_bn(c, nm, d->cs, &d->b_s, &d->b_rm, &d->b_beta); if (rc) return rc; }
@@ -1124,7 +1249,8 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
             const size_t npix = (size_t)R * R;
             nchw_to_nhwc(feats[i] + (size_t)s * npix * d->I, R, R, d->I, fin);
             /* cvt_block: conv3x3+bias -> BN -> LeakyReLU -> Dropout(identity), reference networks_seg.py:64-79 */
-            if (use_wino(R, R, d->F, 0, c->bf16)) conv3x3_wino(fin, R, R, d->I, d->cvt_u, d->F, ya);
+            if (use_wino43(R, R, d->I, d->F, c->bf16)) conv3x3_wino43(fin, R, R, d->I, d->cvt_u, d->F, ya);
+            else if (use_wino(R, R, d->F, 0, c->bf16)) conv3x3_wino(fin, R, R, d->I, d->cvt_u, d->F, ya);
             else conv3x3(fin, R, R, d->I, 0, d->cvt_w, d->F, ya, c->bf16, 1);
             bias_bn_act(ya, npix, d->F, d->cvt_b, d->cvt_s, d->cvt_rm, d->cvt_beta);
             store_bf16(ya, npix * d->F, c->bf16);
@@ -1146,7 +1272,8 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                 else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya, c->bf16, 1);
                 bias_bn_act(ya, np2, d->cs, d->a_b, d->a_s, d->a_rm, d->a_beta);
                 store_bf16(ya, np2 * d->cs, c->bf16);
-                if (use_wino(R2, R2, d->cs, 0, c->bf16)) conv3x3_wino(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
+                if (use_wino43(R2, R2, d->cs, d->cs, c->bf16)) conv3x3_wino43(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
+                else if (use_wino(R2, R2, d->cs, 0, c->bf16)) conv3x3_wino(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
                 else conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb, c->bf16, 1);
                 bias_bn_act(yb, np2, d->cs, d->b_b, d->b_s, d->b_rm, d->b_beta);
 #pragma omp parallel for schedule(static)
