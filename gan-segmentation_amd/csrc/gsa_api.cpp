@@ -327,9 +327,40 @@ std::vector<float> pack_wino(const float* w, int O, int I, float std, bool us, f
     return out;
 }
 
+// Winograd F(4x4,3x3) weights (round 4): U = G g G^T with Lavin & Gray's 6x3 G, evaluated in double on the effective fp32 weights
+// and rounded once (the oracle's pack_wino43 restated), packed [O/16][I/16][f = 6i+j][h][ci][16][c2] with channel = 4*ci + 2*h + c2:
+// the kernel reads the block as two planes of channel pairs (conv3x3_wino43), so a lane's pair is one conflict-free 8-byte read
+std::vector<float> pack_wino43(const float* w, int O, int I, float std, bool us, float lr) {
+    static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    std::vector<float> out((size_t)O * I * 36);
+    const int nblk = I / 16, NG = O / 16;
+    for (int g = 0; g < NG; ++g)
+        for (int cb = 0; cb < nblk; ++cb)
+            for (int ci = 0; ci < 4; ++ci)
+                for (int n = 0; n < 16; ++n)
+                    for (int cg = 0; cg < 4; ++cg) {
+                        const int o = g * 16 + n, ch = cb * 16 + ci * 4 + cg;
+                        const float* wk = w + ((size_t)o * I + ch) * 9;
+                        double k[3][3], r[6][3];
+                        for (int a = 0; a < 3; ++a)
+                            for (int b = 0; b < 3; ++b) k[a][b] = (double)eff(wk[a * 3 + b], std, us, lr);
+                        for (int i = 0; i < 6; ++i)
+                            for (int b = 0; b < 3; ++b) r[i][b] = (G[i][0] * k[0][b] + G[i][1] * k[1][b]) + G[i][2] * k[2][b];
+                        for (int i = 0; i < 6; ++i)
+                            for (int j = 0; j < 6; ++j)
+                                out[(((((((size_t)g * nblk + cb) * 36 + i * 6 + j) * 2 + (cg >> 1)) * 4 + ci) * 16 + n) * 2) + (cg & 1)] =
+                                    (float)((r[i][0] * G[j][0] + r[i][1] * G[j][1]) + r[i][2] * G[j][2]);
+                    }
+    return out;
+}
+// static rule of the F(4x4,3x3) form (gsa_kernels.hip conv_uses_wino43): a Winograd layer with >= 64 input channels and >= 32 px
+inline bool wino43_layer(const gsa_ctx* c, int R, int Cin, int Cout);
+
 // the static rule of the Winograd form (gsa_kernels.hip conv_uses_wino): plain 3x3 convs with outputs >= 64 px, or >= 32 px with
 // at least 64 output channels (fewer tiles than that leave the chip idle: the direct small-tile kernels are faster there), fp32 mode
 inline bool wino_layer(const gsa_ctx* c, int R, int Cout) { return !c->bf16 && (R >= 64 || (R >= 32 && Cout >= 64) || (R >= 16 && Cout >= 256)); }
+inline bool wino43_layer(const gsa_ctx* c, int R, int Cin, int Cout) { return wino43_enabled() && wino_layer(c, R, Cout) && Cin >= 64 && R >= 32; }
 
 // final conv (K,I,3,3) -> [cb][tap][c16][K]
 std::vector<float> pack_final(const float* w, int K, int I) {
@@ -648,7 +679,7 @@ int gsa_generator_commit(gsa_ctx* c) {
         if (int rc = upload_mfma(c, h, &B.w2, T)) return rc;
         B.w2u = nullptr;
         if (wino_layer(c, R, C)) {
-            h = pack_wino(w, C, C, std, us, 1.0f);
+            h = wino43_layer(c, R, C, C) ? pack_wino43(w, C, C, std, us, 1.0f) : pack_wino(w, C, C, std, us, 1.0f);
             if (int rc = upload(c, h, &B.w2u, T)) return rc;
         }
         for (int k = 0; k < 2; ++k) {
@@ -777,7 +808,7 @@ int gsa_decoder_commit(gsa_ctx* c) {
         if (int rc = upload_mfma(c, h, &d.cvt_w, T)) return rc;
         d.cvt_u = d.b_u = nullptr;
         if (wino_layer(c, 4 << i, d.F)) {
-            h = pack_wino(w, d.F, d.I, 1.0f, false, 1.0f);
+            h = wino43_layer(c, 4 << i, d.I, d.F) ? pack_wino43(w, d.F, d.I, 1.0f, false, 1.0f) : pack_wino(w, d.F, d.I, 1.0f, false, 1.0f);
             if (int rc = upload(c, h, &d.cvt_u, T)) return rc;
         }
         snprintf(nm, sizeof nm, "cvt_block_%d.1", i);
@@ -795,7 +826,7 @@ int gsa_decoder_commit(gsa_ctx* c) {
             h = pack_conv3(w, d.cs, d.cs, 1.0f, false, 1.0f);
             if (int rc = upload_mfma(c, h, &d.b_w, T)) return rc;
             if (wino_layer(c, 8 << i, d.cs)) {
-                h = pack_wino(w, d.cs, d.cs, 1.0f, false, 1.0f);
+                h = pack_wino(w, d.cs, d.cs, 1.0f, false, 1.0f);      // conv b carries the residual: never the F(4x4,3x3) form (conv_uses_wino43)
                 if (int rc = upload(c, h, &d.b_u, T)) return rc;
             }
             if (int rc = load_bn(c, pf + "." + std::to_string(second + 1), d.cs, b, &d.b_s, &d.b_beta)) return rc;
@@ -1034,7 +1065,7 @@ static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, 
                 snprintf(layer, sizeof layer, "g.%d.conv_2", R);
                 int rows = conv_stat_rows(R, R, C, n);
                 cp.stat_rows_host = &rows;            // the launcher reports the partial rows it used
-                Launch lp(c, s, conv_kernel_name(cp, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * (conv_uses_wino(cp, EPI_SYNTH, false) ? 4 : 9), 4.0 * (2 * px * C + px), 2.0 * px * C * C * 9);
+                Launch lp(c, s, conv_kernel_name(cp, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * (conv_uses_wino43(cp, EPI_SYNTH, false) ? 2.25 : conv_uses_wino(cp, EPI_SYNTH, false) ? 4 : 9), 4.0 * (2 * px * C + px), 2.0 * px * C * C * 9);
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
                 prow = rows;
             }
@@ -1087,7 +1118,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             cp.wpk = d.cvt_w; cp.wino = d.cvt_u; cp.Cout = d.F; cp.out = c->cvt[i];
             cp.bn_s = d.cvt_s; cp.bn_beta = d.cvt_beta;
             snprintf(layer, sizeof layer, "d.cvt_%d", i);
-            Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * (conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px * (d.I + d.F), 2.0 * px * d.F * d.I * 9);
+            Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * (conv_uses_wino43(cp, EPI_DEC, false) ? 2.25 : conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px * (d.I + d.F), 2.0 * px * d.F * d.I * 9);
             HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
         }
         if (!d.is_last) {
@@ -1125,7 +1156,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 else if (i == s0) { cp.resid = c->cvt[i]; cp.resid_up = 1; }   // identity shortcut: the upsampled input itself
                 else { cp.resid = c->prev[i - 1]; cp.resid1 = c->cvt[i]; cp.res_c0 = d.F; cp.resid_up = 1; }   // ... over concat(prev, cvt)
                 snprintf(layer, sizeof layer, "d.main_%d.b", i);
-                Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * (conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px2 * d.cs * 3, 2.0 * px2 * d.cs * d.cs * 9);
+                Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px2 * d.cs * d.cs * (conv_uses_wino43(cp, EPI_DEC, false) ? 2.25 : conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px2 * d.cs * 3, 2.0 * px2 * d.cs * d.cs * 9);
                 HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
             }
         } else {

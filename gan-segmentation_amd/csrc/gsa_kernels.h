@@ -31,6 +31,7 @@ struct ConvParams {
     int H, W;        // output size
     const float* wpk;   // packed weights [Cout/16][Cin/16][tap][ci][16][cg]
     const float* wino;  // or null: the same conv in Winograd F(2x2,3x3) form, U packed [Cout/16][Cin/16][f16][ci][16][cg]
+                        // (F(4x4,3x3) layers, conv_uses_wino43: [Cout/16][Cin/16][f36][ci][16][cg])
     int Cout;           // total output channels
     float* out;         // NHWC
     // EPI_SYNTH: AddNoise -> Bias -> LeakyReLU -> statistics
@@ -79,6 +80,8 @@ struct FinalizeParams {
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);
 bool conv_uses_ws(const ConvParams& p, int epi, bool shortcut, int n);
 bool conv_uses_ksplit(const ConvParams& p, bool shortcut);         // true: 4-way K split form (static rule: layer shape only)
+bool conv_uses_wino43(const ConvParams& p, int epi, bool shortcut); // true: Winograd F(4x4,3x3) form (static rule: layer shape only; p.wino then holds the 36-frequency panel)
+bool wino43_enabled();                                              // GSA_WINO43 != 0
 bool conv_uses_wino(const ConvParams& p, int epi, bool shortcut);   // true: Winograd form (static rule: layer shape only)   // true: wave-specialised kernel, no partial rows
 hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);   // deconv4x4s2 / sub-pixel up+conv
 bool subpixel_uses_wino(const ConvParams& p);                      // true: Winograd F(2x2,2x2) form (static rule: fp32 mode): 9 products per 2x2 class outputs instead of 163x3

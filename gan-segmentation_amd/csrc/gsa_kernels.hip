@@ -1568,6 +1568,362 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
 }
 
 // ------------------------------------------------------------------------------------------
+// conv3x3 (pad 1, stride 1, one source) in WINOGRAD F(4x4, 3x3) form on v_mfma_f32_16x16x4_f32 (round 4).
+//
+//     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A      per 4x4 OUTPUT tile from its 6x6 input patch:
+//     36 products per 16 outputs (2.25 per output) where F(2x2,3x3) needs 64 (4 per output) and the direct form 144 (9).
+//
+// Thirty-six GEMMs  M_f[cout][tile] = sum_c U_f[c][cout] V_f[tile][c],  f = 6i+j:  the weights are the A operand (M = 16 output
+// channels), the transformed patches the B operand (N = the 16 tiles of a 16x16 output region), K = input channels -- 144 MFMAs
+// per 16-channel block and 256 output pixels where conv3x3_wino issues 256.  Canonical arithmetic: oracle/c/gsa_oracle.c
+// conv3x3_wino43 (transform op order with its fmaf forms; U = G g G^T in double on the host, rounded once; each M_f one k-ordered
+// fmaf chain = the MFMA): reproduced BIT FOR BIT.  Static rule (layer shape only): conv_uses_wino43.
+//
+// One wave = one 16x16 output region; lane (i16, kq) owns tile (ty, tx) = (i16 >> 2, i16 & 3) and k slot kq, and -- weights being
+// the A operand -- leaves the MFMAs with FOUR CONSECUTIVE OUTPUT CHANNELS (4*kq + r) of ITS tile in an accumulator vector: the
+// output transform works on channel vectors, every output pixel is one 16-byte NHWC store, the statistics' x-quads are in-lane.
+// 36 accumulator vectors + 36 patch vectors do not fit two waves per SIMD: the workgroup is FOUR waves, one per SIMD, with the whole
+// register file (launch bound 1) -- what it costs (no second wave to hide a wave's LDS latency) against 1.78x fewer MFMAs is the
+// measurement DESIGN.md reports.
+//   * activation image: WAVE-PRIVATE (18x18 halo pixels x 16 channels, staged by the wave's own lanes as 16-byte chunks with the
+//     AdaIN fma on the way, 21 rounds): no workgroup barrier guards it, only the wave's own LDS counter.  A tile's x stride is
+//     4 pixels = 256 bytes = all 64 banks, so a pixel's four 16-byte chunks are ROTATED by (x >> 2): with the row stride 18*16+4
+//     floats every ds_read_b128 of the 6x6 patch is then bank-conflict free (brute-forced over the ds_read_b128 lane groups);
+//   * weights: the 36 KB panel of (16 couts, 16-channel block) is shared by the four waves, double-buffered in LDS and filled by
+//     LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction, no registers) one item ahead; ONE barrier per item.
+// blockIdx.y = output-channel group; a workgroup walks a contiguous (XCD-aware) range of 4-tile items of its group.
+#ifndef GSA_W43_PK
+#define GSA_W43_PK 1
+#endif
+__device__ __forceinline__ f32x2 pk_fma2s(f32x2 a, f32x2 c, f32x2 b) {      // a * c + b, c = a constant pair in scalar registers
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(c), "v"(b));
+    return r;
+}
+// The F(4x4,3x3) transforms on channel PAIRS (v_pk_*_f32: one instruction per two channels; constants as a scalar register pair).
+// c is a power of two or 5; fmaf(c, a, b), a + b, a - b exactly as the oracle's wino43_in / wino43_out write them.
+__device__ __forceinline__ f32x2 fma2c(float c, f32x2 a, f32x2 b) {
+#if GSA_W43_PK
+    return pk_fma2s(a, f32x2{c, c}, b);
+#else
+    return f32x2{fmaf(c, a.x, b.x), fmaf(c, a.y, b.y)};
+#endif
+}
+__device__ __forceinline__ f32x2 add2c(f32x2 a, f32x2 b) {
+#if GSA_W43_PK
+    return pk_add2(a, b);
+#else
+    return a + b;
+#endif
+}
+__device__ __forceinline__ f32x2 sub2c(f32x2 a, f32x2 b) {
+#if GSA_W43_PK
+    return pk_sub2(a, b);
+#else
+    return a - b;
+#endif
+}
+// input transform of one 6-vector (oracle wino43_in): 12 operations
+__device__ __forceinline__ void w43_in(const f32x2 (&d)[6], f32x2 (&t)[6]) {
+    const f32x2 a = fma2c(-4.0f, d[2], d[4]), b = fma2c(-4.0f, d[1], d[3]);
+    const f32x2 c = sub2c(d[4], d[2]), e = sub2c(d[3], d[1]);
+    t[0] = fma2c(4.0f, d[0], fma2c(-5.0f, d[2], d[4]));
+    t[1] = add2c(a, b);
+    t[2] = sub2c(a, b);
+    t[3] = fma2c(2.0f, e, c);
+    t[4] = fma2c(-2.0f, e, c);
+    t[5] = fma2c(4.0f, d[1], fma2c(-5.0f, d[3], d[5]));
+}
+// output transform of one 6-vector (oracle wino43_out): 10 operations; on the lane's FOUR output channels (two pairs)
+__device__ __forceinline__ void w43_out2(const f32x2 (&m)[6], f32x2 (&y)[4]) {
+    const f32x2 pp = add2c(m[1], m[2]), qq = sub2c(m[1], m[2]), rr = add2c(m[3], m[4]), ss = sub2c(m[3], m[4]);
+    y[0] = add2c(add2c(m[0], pp), rr);
+    y[1] = fma2c(2.0f, ss, qq);
+    y[2] = fma2c(4.0f, rr, pp);
+    y[3] = add2c(fma2c(8.0f, ss, qq), m[5]);
+}
+__device__ __forceinline__ void w43_out(const f32x4 (&m)[6], f32x4 (&y)[4]) {
+    f32x2 lo[6], hi[6], ylo[4], yhi[4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { lo[i] = m[i].xy; hi[i] = m[i].zw; }
+    w43_out2(lo, ylo);
+    w43_out2(hi, yhi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = f32x4{ylo[i].x, ylo[i].y, yhi[i].x, yhi[i].y};
+}
+__device__ __forceinline__ void valu_settle6(f32x2 (&v)[6]) {
+#if GSA_W43_PK
+    asm("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));      // VALU result -> MFMA operand: 2 wait states
+#endif
+}
+__device__ __forceinline__ void mfma_settle18(f32x4* a) {
+#if GSA_W43_PK
+    asm("s_nop 7\n\ts_nop 3"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+          "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]));
+#endif
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino43(ConvParams p) {
+    // one image per wave = two PLANES of channel pairs (plane h holds the channels 4*kq + 2h, 4*kq + 2h + 1 of every pixel, 8 floats
+    // per pixel): the patch is read and transformed one plane at a time (72 instead of 144 registers of transformed patch)
+    constexpr int LH = 18, LW = 18, RS = LW * 8 + 2, PL = LH * RS, IMG = 2 * PL;      // floats
+    constexpr int SEG = 36 * 256;                                            // U floats per (16 couts, 16-channel block): [f][h][kq][16][2]
+    constexpr int NR = (LH * LW * 4 + 63) / 64;                              // 21 staging rounds of 64 chunks
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    float* sA = smem + wave * IMG;
+    float* sB = smem + 4 * IMG;                   // [2][SEG]
+    const int nblk = p.C0 >> 4;
+    const int g = blockIdx.y;
+    // contiguous range of the group's 4-tile items, order (n, ty, tx)
+    const int witems = (p.total_tiles + 3) >> 2;
+    const int wchunk = (witems + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int w_begin = xcd_block(blockIdx.x, gridDim.x) * wchunk;
+    const int w_end = min(witems, w_begin + wchunk);
+    if (w_begin >= w_end) return;
+    const int tpi = p.tiles_x * p.tiles_y;
+
+    // ---- staging geometry: chunk q = lane + 64k of the wave's halo tile = pixel q0 + 16k (q0 = lane >> 2), part lane & 3.
+    // idx = 16k + q0 = 18*L_k + B_k + q0 with compile-time L_k, B_k: (ly, lx) = (L_k + wrap, B_k + q0 - 18*wrap), wrap = B_k + q0 >= 18
+    const int part = lane & 3, q0 = lane >> 2;
+    int st_rel[NR];                               // float offset of the chunk's pixel from the halo origin in the source tensor: (ly*W + lx) * C0
+    int st_lds[(NR + 1) / 2];                     // two 16-bit LDS offsets (floats, plane 0) per register
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int Lk = (16 * k) / LW, Bk = (16 * k) % LW;
+        const int wrap = (Bk + q0 >= LW) ? 1 : 0;
+        const int ly = Lk + wrap, lx = Bk + q0 - LW * wrap;
+        st_rel[k] = (ly * p.W + lx) * p.C0;
+        const int lo = ly * RS + lx * 8 + ((part + (lx >> 2)) & 3) * 2;
+        if (k & 1) st_lds[k >> 1] |= lo << 16; else st_lds[k >> 1] = lo;
+    }
+    const unsigned valid_mask = q0 < 4 ? (1u << NR) - 1u : (1u << (NR - 1)) - 1u;      // round 20 holds pixels 320..323 only
+    // per tile: which of this lane's chunks lie inside the image (bit k); interior tiles: every valid one
+    auto tile_mask = [&](int y0, int x0) {
+        if (!(y0 == 0 || x0 == 0 || y0 + 16 == p.H || x0 + 16 == p.W)) return valid_mask;      // wave-uniform
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int Lk = (16 * k) / LW, Bk = (16 * k) % LW;
+            const int wrap = (Bk + q0 >= LW) ? 1 : 0;
+            const int ly = Lk + wrap, lx = Bk + q0 - LW * wrap;
+            if ((unsigned)(y0 + ly - 1) < (unsigned)p.H && (unsigned)(x0 + lx - 1) < (unsigned)p.W) m |= 1u << k;
+        }
+        return m & valid_mask;
+    };
+    // ---- patch geometry
+    const int ty = i16 >> 2, tx = i16 & 3;
+    const int abase = (4 * ty) * RS + (4 * tx) * 8;
+    const int aoff0 = ((kq + tx) & 3) * 2, aoff1 = ((kq + tx + 1) & 3) * 2;        // pair rotation of columns 0-3 / 4-5 of the patch
+    const int bbase = (kq * 16 + i16) * 2;
+    const float* wgrp = p.wpk + (size_t)g * nblk * SEG;
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int f = 0; f < 36; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct WT { int n, y0, x0; bool on; unsigned mask; };
+    auto tile_of = [&](int wi) {
+        WT t;
+        const int idx = wi * 4 + wave;
+        t.on = idx < p.total_tiles;
+        const int id = t.on ? idx : 0;
+        t.n = id / tpi;
+        const int r = id - t.n * tpi;
+        t.y0 = (r / p.tiles_x) * 16; t.x0 = (r % p.tiles_x) * 16;
+        t.mask = tile_mask(t.y0, t.x0);
+        return t;
+    };
+    f32x4 ra[NR], raff[4];
+    const bool has_aff = p.aff0 != nullptr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) raff[c] = f32x4{0.f, 1.f, 0.f, 0.f};
+    auto load_weights = [&](int cb, int buf) {      // 36 pieces of 1 KB, 9 per wave, straight into LDS
+        const float* src = wgrp + (size_t)cb * SEG + lane * 4;
+        float* dst = sB + buf * SEG;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int piece = wave + 4 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256),
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+        }
+    };
+    auto load_item = [&](const WT& t, int cb) {
+        if (!t.on) return;
+        // one wave-uniform base + a 32-bit per-lane float offset (the tensors of these layers are far below 2^31 floats)
+        const float* src = p.src0 + cb * 16 + part * 4;
+        const int base = ((t.n * p.H + t.y0 - 1) * p.W + t.x0 - 1) * p.C0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int off = (t.mask >> k) & 1u ? base + st_rel[k] : 0;      // unconditional load; an outside pixel is zeroed at the write
+            ra[k] = *reinterpret_cast<const f32x4*>(src + off);
+        }
+        if (has_aff) load_aff4(raff, p.aff0, (size_t)t.n * p.C0 + cb * 16 + part * 4);
+    };
+    auto write_item = [&](const WT& t) {
+        if (!t.on) return;
+        const bool edge = t.mask != valid_mask;      // per lane; only costs the selects
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            f32x4 v = ra[k];
+            if (has_aff) {                       // wave-uniform: a stand-alone decoder call has no AdaIN on its inputs
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = fmaf(ra[k][c], raff[c][1], raff[c][2]);
+            }
+            if (edge && !((t.mask >> k) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int lo = (k & 1) ? (st_lds[k >> 1] >> 16) & 0xffff : st_lds[k >> 1] & 0xffff;
+            if (k < NR - 1 || q0 < 4) {
+                *reinterpret_cast<f32x2*>(sA + lo) = v.xy;
+                *reinterpret_cast<f32x2*>(sA + PL + lo) = v.zw;
+            }
+        }
+    };
+
+    // ---- epilogue: lane -> tile (ty, tx), output channels co4 .. co4+3
+    const int co4 = g * 16 + kq * 4;
+    f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f}, e1 = e0;
+    if (EPI == EPI_SYNTH) { e0 = *reinterpret_cast<const f32x4*>(p.nscale + co4); e1 = *reinterpret_cast<const f32x4*>(p.nbias + co4); }
+    if (EPI == EPI_DEC) { e0 = *reinterpret_cast<const f32x4*>(p.bn_s + co4); e1 = *reinterpret_cast<const f32x4*>(p.bn_beta + co4); }
+    float4 nzs[EPI == EPI_SYNTH ? 4 : 1];
+    auto epilogue_loads = [&](const WT& t) {
+        if (EPI == EPI_SYNTH && t.on) {
+            const float* nz = p.noise + ((size_t)(t.n * p.H + t.y0 + 4 * ty) * p.W + t.x0 + 4 * tx);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nzs[i] = *reinterpret_cast<const float4*>(nz + i * p.W);
+        }
+    };
+    const int s2 = stat_s2(p.H * p.W);
+    unsigned long long dI1[4], dI2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dI1[r] = dI2[r] = 0ull;
+    auto flush_stats = [&](int n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            unsigned long long I1 = dI1[r], I2 = dI2[r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { I1 += shfl_xor_u64(I1, m); I2 += shfl_xor_u64(I2, m); }
+            if (i16 == 0) {
+                StatPart* a = p.partials + ((size_t)n * p.prow + (blockIdx.x & (kDirectRows - 1))) * p.Cout + co4 + r;
+                atomicAdd(&a->s1, I1);
+                atomicAdd(&a->s2, I2);
+            }
+            dI1[r] = dI2[r] = 0ull;
+        }
+    };
+    auto epilogue = [&](const WT& t) {
+        // output transform Y = A^T M A: down the columns of M, then along the rows; vectors = the lane's four output channels
+        mfma_settle18(acc);
+        mfma_settle18(acc + 18);
+        f32x4 sr[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const f32x4 m[6] = {acc[j], acc[6 + j], acc[12 + j], acc[18 + j], acc[24 + j], acc[30 + j]};
+            f32x4 y[4];
+            w43_out(m, y);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sr[i][j] = y[i];
+        }
+#pragma unroll
+        for (int f = 0; f < 36; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float* orow = p.out + ((size_t)(t.n * p.H + t.y0 + 4 * ty) * p.W + t.x0 + 4 * tx) * p.Cout + co4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v[4];
+            w43_out(sr[i], v);
+            if (EPI == EPI_SYNTH) {
+                const float nzv[4] = {nzs[i].x, nzs[i].y, nzs[i].z, nzs[i].w};
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float tn = e0[r] * nzv[x];
+                        v[x][r] = lrelu((v[x][r] + tn) + e1[r]);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sq = (v[0][r] + v[1][r]) + (v[2][r] + v[3][r]);
+                    const float qq = (v[0][r] * v[0][r] + v[1][r] * v[1][r]) + (v[2][r] * v[2][r] + v[3][r] * v[3][r]);
+                    dI1[r] += to_fixed(sq, kStatScale1);
+                    dI2[r] += to_fixed_sq(qq, s2);
+                }
+            }
+            if (EPI == EPI_DEC) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[x][r] = lrelu(fmaf(v[x][r], e0[r], e1[r]));
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) *reinterpret_cast<f32x4*>(orow + ((size_t)i * p.W + x) * p.Cout) = v[x];
+        }
+    };
+
+    auto compute = [&](int buf) {
+        __builtin_amdgcn_s_setprio(GSA_MFMA_PRIO);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {            // channel pairs (4kq + 2h, 4kq + 2h + 1): MFMAs cg = 2h, 2h + 1 of every frequency, in that order
+            const float* a_img = sA + h * PL + abase;
+            const float* b_img = sB + buf * SEG + h * 128 + bbase;
+            // input transform V = B^T d B: down the columns of the 6x6 patch, then along the rows
+            f32x2 tt[6][6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                f32x2 d[6], col[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x2*>(a_img + r * RS + c * 8 + (c < 4 ? aoff0 : aoff1));
+                w43_in(d, col);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) tt[i][c] = col[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                f32x2 V[6];
+                w43_in(tt[i], V);
+                valu_settle6(V);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const f32x2 b = *reinterpret_cast<const f32x2*>(b_img + (i * 6 + j) * 256);
+                    acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, V[j].x, acc[i * 6 + j], 0, 0, 0);
+                    acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, V[j].y, acc[i * 6 + j], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- items (4-tile item, channel block).  Item `it` is multiplied out of the wave's image and weight buffer it & 1 while the
+    // loads of item it+1 (activations -> registers, weights -> the other LDS buffer) are in flight.
+    const int total_items = (w_end - w_begin) * nblk;
+    int wi = w_begin, cb = 0;
+    WT tc = tile_of(wi);
+    int n_stats = tc.n;
+    load_weights(0, 0);
+    load_item(tc, 0);
+    for (int it = 0; it < total_items; ++it) {
+        write_item(tc);                          // waits for the item's loads (activations AND this wave's weight pieces)
+        __syncthreads();                         // every wave's weight pieces of buffer it & 1 have landed; buffer (it+1) & 1 is free
+        // next item
+        int wi2 = wi, cb2 = cb + 1;
+        WT tn = tc;
+        if (cb2 == nblk) { cb2 = 0; ++wi2; if (wi2 < w_end) tn = tile_of(wi2); }
+        const bool has_next = it + 1 < total_items;
+        if (has_next) { load_weights(cb2, (it + 1) & 1); load_item(tn, cb2); }
+        if (cb == nblk - 1) epilogue_loads(tc);
+        if (tc.on) compute(it & 1);
+        if (cb == nblk - 1 && tc.on) {
+            epilogue(tc);
+            if (EPI == EPI_SYNTH && (!has_next || !tn.on || tn.n != tc.n)) flush_stats(tc.n);
+        }
+        wi = wi2; cb = cb2; tc = tn;
+    }
+    (void)n_stats;
+}
+
+// ------------------------------------------------------------------------------------------
 // Winograd F(2x2, 2x2) form of the stride-2 parity-class convolutions (round 3; canonical arithmetic:
 // oracle/c/gsa_oracle.c deconv4x4s2_wino).  A parity class (py, px) of the 4x4 stride-2 transposed
 // convolution is a 2x2-tap stride-1 convolution; per 2x2 class outputs the Winograd form needs 9 products instead of 16:
@@ -3416,6 +3772,54 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- Winograd F(4x4,3x3) form (round 4).  Static rule, part of the canonical arithmetic (oracle/c/gsa_oracle.c use_wino43): a
+// layer that takes the Winograd form, has at least 64 input channels (the streamed-weight layers) and an output of at least 32 px.
+// GSA_WINO43=0 keeps F(2x2,3x3) there -- a different arithmetic (the oracle has GSAO_WINO43=0), for timing and A/B only.
+bool wino43_enabled() {
+    static const bool enabled = !(getenv("GSA_WINO43") && atoi(getenv("GSA_WINO43")) == 0);
+    return enabled;
+}
+bool conv_uses_wino43(const ConvParams& p, int epi, bool sc) {
+    return wino43_enabled() && conv_uses_wino(p, epi, sc) && p.C0 >= 64 && p.H >= 32 && p.resid == nullptr;
+}
+
+template <int EPI>
+static hipError_t launch_wino43_t(const ConvParams& p, int n, hipStream_t s) {
+    constexpr int RS = 18 * 16 + 4, SEG = 36 * 256;
+    const size_t lds = sizeof(float) * (4 * 18 * RS + 2 * SEG);
+    auto kern = conv3x3_wino43<EPI>;
+    if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
+    static LaunchState states[kMaxDevices];
+    int num_cus = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        hipError_t e = prepare_kernel(kern, states[p.device]);
+        if (e != hipSuccess) return e;
+        num_cus = device_cus(p.device);
+    }
+    ConvParams q = p;
+    q.wpk = p.wino;
+    q.tiles_x = p.W / 16;
+    q.tiles_y = p.H / 16;
+    q.groups = p.Cout / 16;
+    q.total_tiles = q.tiles_x * q.tiles_y * n;         // 16x16 wave tiles per output-channel group
+    const int witems = (q.total_tiles + 3) / 4;        // a workgroup item = 4 wave tiles
+    // one workgroup per CU (the whole register file per wave); a workgroup stays inside its channel group and walks a contiguous
+    // range of items; workgroup (x, g) has the linear index x + g * gx: with gx a multiple of 8 the groups of a range share an XCD's L2
+    const int slots = std::max(1, num_cus / q.groups);
+    const int gx = std::min(witems, slots);
+    q.stats_direct = 1;
+    q.prow = kDirectRows;      // the sums go straight to kDirectRows zeroed rows per sample (finalize_kernel clears what it read)
+    if (p.stat_rows_host) *p.stat_rows_host = q.prow;
+    hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256), lds, s, q);
+    return hipGetLastError();
+}
+
+static hipError_t launch_wino43(const ConvParams& p, int epi, int n, hipStream_t s) {
+    if (epi == EPI_SYNTH) return launch_wino43_t<EPI_SYNTH>(p, n, s);
+    return launch_wino43_t<EPI_DEC>(p, n, s);
+}
+
 // staging form of the Winograd kernel: 16-byte chunks from 64 input channels on, whole pixels below (measured; speed only)
 static bool wino_chunk(const ConvParams& p) {
     static const int forced = getenv("GSA_WINO_CHUNK") ? atoi(getenv("GSA_WINO_CHUNK")) : -1;
@@ -3453,6 +3857,10 @@ static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s
 // exact C++ name of the instantiation launch_conv3x3 picks (profile labels spell kernels as rocprofv3 prints them)
 const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     static thread_local char buf[128];
+    if (conv_uses_wino43(p, epi, sc)) {
+        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino43<%d>(gsa::ConvParams)", epi);
+        return buf;
+    }
     if (conv_uses_wino(p, epi, sc)) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d, %d, %s, %s, %d>(gsa::ConvParams)", epi, wino_nt(p), wino_chunk(p) ? "true" : "false", p.aff0 ? "true" : "false", wino_gw(p));
         return buf;
@@ -3469,6 +3877,7 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
 
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     if (p.H != p.W || (p.H & (p.H - 1)) || p.H < 4 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
+    if (conv_uses_wino43(p, epi, sc)) return launch_wino43(p, epi, n, s);
     if (conv_uses_wino(p, epi, sc)) return launch_wino(p, epi, n, s);
     if (conv_uses_ksplit(p, sc)) return launch_ksplit(p, epi, n, s);
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);

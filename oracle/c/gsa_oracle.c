@@ -287,8 +287,9 @@ static float* pack_wino(const float* w, int O, int I, float std, int use_std, fl
 }
 
 /* ---- Winograd F(4x4, 3x3) form (round 4) -------------------------------------------------------------------------
- * Rule (static, by layer shape only): a layer that takes the Winograd form above AND has at least 64 input channels (the
- * streamed-weight layers: synthesis conv_2 at 16^2-256^2, decoder cvt at 64^2-256^2) is evaluated per 4x4 OUTPUT tile from its
+ * Rule (static, by layer shape only): a layer WITHOUT a residual epilogue (synthesis conv_2, decoder cvt -- never ResBlock conv b)
+ * that takes the Winograd form above, has at least 64 input channels and an output of at least 32 px (FFHQ: synthesis conv_2 at
+ * 32^2-256^2, decoder cvt at 64^2-256^2) is evaluated per 4x4 OUTPUT tile from its
  * 6x6 input patch: 36 products per 16 outputs instead of 64 (F(2x2,3x3)) or 144 (direct).  Lavin & Gray's matrices
  *     B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
  *     G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
@@ -308,8 +309,8 @@ static float* pack_wino(const float* w, int O, int I, float std, int use_std, fl
 #endif
 static int g_wino43 = -1;
 static int use_wino43(int H, int W, int Cin, int Cout, int bf) {
-    if (g_wino43 < 0) { const char* e = getenv("GSAO_WINO43"); g_wino43 = e ? atoi(e) : 0;   /* off until the HIP kernel carries the same rule */ }
-    return g_wino43 && use_wino(H, W, Cout, 0, bf) && Cin >= 64;
+    if (g_wino43 < 0) { const char* e = getenv("GSAO_WINO43"); g_wino43 = e ? atoi(e) : 1; }
+    return g_wino43 && use_wino(H, W, Cout, 0, bf) && Cin >= 64 && H >= 32;
 }
 
 /* conv OIHW (O,I,3,3) -> U packed [(cb*36 + f)*CB + c][O], f = 6*i + j */
@@ -1188,7 +1189,7 @@ GSAO_API int gsao_decoder_commit(gsao_ctx* c) {
             { int rc = load_bn(c, nm, d->cs, &d->a_s, &d->a_rm, &d->a_beta); if (rc) return rc; }
             snprintf(nm, sizeof nm, "%s.%d.weight", pf, second); NEED(t, nm, (int64_t)d->cs * d->cs * 9, &w);
             d->b_w = pack_conv(w, d->cs, d->cs, 3, 1.0f, 0, 1.0f);
-            d->b_u = pack_wino_any(w, d->cs, d->cs, 1.0f, 0, 1.0f, 8 << i, c->bf16);
+            d->b_u = pack_wino(w, d->cs, d->cs, 1.0f, 0, 1.0f);      /* conv b (residual epilogue) keeps F(2x2,3x3) */
             snprintf(nm, sizeof nm, "%s.%d.bias", pf, second); NEED(t, nm, d->cs, &b); d->b_b = copy_plain(b, d->cs);
             snprintf(nm, sizeof nm, "%s.%d", pf, second + 1);
             { int rc = load_bn(c, nm, d->cs, &d->b_s, &d->b_rm, &d->b_beta); if (rc) return rc; }
@@ -1272,8 +1273,7 @@ GSAO_API int gsao_decoder_forward(gsao_ctx* c, void* stream, int32_t n, const fl
                 else conv3x3(cat, R, R, d->in_c, 1, d->a_w, d->cs, ya, c->bf16, 1);
                 bias_bn_act(ya, np2, d->cs, d->a_b, d->a_s, d->a_rm, d->a_beta);
                 store_bf16(ya, np2 * d->cs, c->bf16);
-                if (use_wino43(R2, R2, d->cs, d->cs, c->bf16)) conv3x3_wino43(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
-                else if (use_wino(R2, R2, d->cs, 0, c->bf16)) conv3x3_wino(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
+                if (use_wino(R2, R2, d->cs, 0, c->bf16)) conv3x3_wino(ya, R2, R2, d->cs, d->b_u, d->cs, yb);
                 else conv3x3(ya, R2, R2, d->cs, 0, d->b_w, d->cs, yb, c->bf16, 1);
                 bias_bn_act(yb, np2, d->cs, d->b_b, d->b_s, d->b_rm, d->b_beta);
 #pragma omp parallel for schedule(static)
