@@ -111,6 +111,7 @@ struct gsa_ctx {
     unsigned* stat_tickets = nullptr;
     unsigned* map_ctl = nullptr;            // fused mapping network: launch number, error word
     unsigned long long* map_ll[2] = {nullptr, nullptr};   // its {value, tag} exchange buffers
+    float* zeros = nullptr;                 // 256 bytes of zeros (gsa_create): the out-of-image source of conv3x3_wino43's LDS-DMA halo gather
     unsigned long long* stamps = nullptr;   // diagnostic build only
     float* din[kMaxLevels] = {nullptr};
     float* cvt[kMaxLevels] = {nullptr};
@@ -328,19 +329,19 @@ std::vector<float> pack_wino(const float* w, int O, int I, float std, bool us, f
 }
 
 // Winograd F(4x4,3x3) weights (round 4): U = G g G^T with Lavin & Gray's 6x3 G, evaluated in double on the effective fp32 weights
-// and rounded once (the oracle's pack_wino43 restated), packed [O/16][I/16][f = 6i+j][h][ci][16][c2] with channel = 4*ci + 2*h + c2:
-// the kernel reads the block as two planes of channel pairs (conv3x3_wino43), so a lane's pair is one conflict-free 8-byte read
+// and rounded once (the oracle's pack_wino43 restated), packed per 8-CHANNEL block [O/16][I/8][f = 6i+j][kq][16][j2] with
+// channel = 8b + 2kq + j2 (the K order of these layers: conv3x3_wino43): a lane's weight pair is one 8-byte LDS read
 std::vector<float> pack_wino43(const float* w, int O, int I, float std, bool us, float lr) {
     static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
     std::vector<float> out((size_t)O * I * 36);
-    const int nblk = I / 16, NG = O / 16;
+    const int nblk = I / 8, NG = O / 16;
     for (int g = 0; g < NG; ++g)
         for (int cb = 0; cb < nblk; ++cb)
-            for (int ci = 0; ci < 4; ++ci)
+            for (int kq = 0; kq < 4; ++kq)
                 for (int n = 0; n < 16; ++n)
-                    for (int cg = 0; cg < 4; ++cg) {
-                        const int o = g * 16 + n, ch = cb * 16 + ci * 4 + cg;
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const int o = g * 16 + n, ch = cb * 8 + kq * 2 + j2;
                         const float* wk = w + ((size_t)o * I + ch) * 9;
                         double k[3][3], r[6][3];
                         for (int a = 0; a < 3; ++a)
@@ -349,7 +350,7 @@ std::vector<float> pack_wino43(const float* w, int O, int I, float std, bool us,
                             for (int b = 0; b < 3; ++b) r[i][b] = (G[i][0] * k[0][b] + G[i][1] * k[1][b]) + G[i][2] * k[2][b];
                         for (int i = 0; i < 6; ++i)
                             for (int j = 0; j < 6; ++j)
-                                out[(((((((size_t)g * nblk + cb) * 36 + i * 6 + j) * 2 + (cg >> 1)) * 4 + ci) * 16 + n) * 2) + (cg & 1)] =
+                                out[((((((size_t)g * nblk + cb) * 36 + i * 6 + j) * 4 + kq) * 16 + n) * 2) + j2] =
                                     (float)((r[i][0] * G[j][0] + r[i][1] * G[j][1]) + r[i][2] * G[j][2]);
                     }
     return out;
@@ -549,6 +550,13 @@ int gsa_create(int device, gsa_ctx** out) {
         delete c;
         return rc;
     }
+    if (e == hipSuccess) e = hipMalloc((void**)&c->zeros, 256);
+    if (e == hipSuccess) e = hipMemset(c->zeros, 0, 256);
+    if (e != hipSuccess) {
+        const int rc = fail(nullptr, GSA_ERR_HIP, "allocating the zero page: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
     if (const char* v = getenv("GSA_SIDE_LEVELS")) c->side_levels = atoi(v);
     if (const char* v = getenv("GSA_DBG")) c->dbg = atoi(v);
     if (const char* v = getenv("GSA_PRIO")) c->prio = atoi(v);
@@ -569,6 +577,7 @@ void gsa_destroy(gsa_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->zeros) (void)hipFree(c->zeros);
     delete c;
 }
 
@@ -1031,7 +1040,7 @@ static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, 
                 if (!B.has_conv1) {
                     pp.src = c->constant; pp.src_per_sample = 0; pp.blur = nullptr;
                 } else {
-                    ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
+                    ConvParams cp{}; cp.stamps = c->stamps; cp.zeros = c->zeros; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
                     cp.src0 = c->x2[l - 1]; cp.aff0 = c->aff2[l - 1]; cp.C0 = Cin;
                     cp.Hs = R / 2; cp.Ws = R / 2; cp.H = R; cp.W = R;
                     cp.wpk = B.w1; cp.Cout = C; cp.out = c->t_raw;
@@ -1057,7 +1066,7 @@ static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, 
                 HIP_TRY(launch_post(pp, n, s));
                 prow = post_rows_used(pp);
             } else {
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.zeros = c->zeros; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
                 cp.src0 = c->x1; cp.aff0 = c->aff1; cp.C0 = C;
                 cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
                 cp.wpk = B.w2; cp.wino = B.w2u; cp.Cout = C; cp.out = c->x2[l];
@@ -1112,7 +1121,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
         const double px = N * R * R;
         if (wait_levels) HIP_TRY(hipStreamWaitEvent(s, c->ev_level[i], 0));   // generator feature i is ready
         {   // cvt_block: conv3x3+bias -> BN -> LeakyReLU (Dropout is identity at inference)
-            ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
+            ConvParams cp{}; cp.stamps = c->stamps; cp.zeros = c->zeros; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
             cp.src0 = fsrc[i]; cp.aff0 = faff ? faff[i] : nullptr; cp.C0 = d.I;
             cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
             cp.wpk = d.cvt_w; cp.wino = d.cvt_u; cp.Cout = d.F; cp.out = c->cvt[i];
@@ -1125,7 +1134,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
             const int R2 = 2 * R;
             const double px2 = 4 * px;
             {   // ResBlock conv a (+ fused 1x1 shortcut) on nearest-x2(concat(prev, cvt))
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.zeros = c->zeros; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
                 if (i > s0) { cp.src0 = c->prev[i - 1]; cp.C0 = d.F; cp.src1 = c->cvt[i]; cp.C1 = d.F; }
                 else { cp.src0 = c->cvt[i]; cp.C0 = d.F; }
                 cp.Hs = R; cp.Ws = R; cp.up = 1; cp.H = R2; cp.W = R2;
@@ -1147,7 +1156,7 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
                 }
             }
             {   // ResBlock conv b, + shortcut
-                ConvParams cp{}; cp.stamps = c->stamps; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
+                ConvParams cp{}; cp.stamps = c->stamps; cp.zeros = c->zeros; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
                 cp.src0 = c->ya[i]; cp.C0 = d.cs;
                 cp.Hs = R2; cp.Ws = R2; cp.H = R2; cp.W = R2;
                 cp.wpk = d.b_w; cp.wino = d.b_u; cp.Cout = d.cs; cp.out = c->prev[i];

@@ -31,7 +31,7 @@ struct ConvParams {
     int H, W;        // output size
     const float* wpk;   // packed weights [Cout/16][Cin/16][tap][ci][16][cg]
     const float* wino;  // or null: the same conv in Winograd F(2x2,3x3) form, U packed [Cout/16][Cin/16][f16][ci][16][cg]
-                        // (F(4x4,3x3) layers, conv_uses_wino43: [Cout/16][Cin/16][f36][ci][16][cg])
+                        // (F(4x4,3x3) layers, conv_uses_wino43: [Cout/16][Cin/8][f36][kq][16][2], channel 8b + 2kq + j)
     int Cout;           // total output channels
     float* out;         // NHWC
     // EPI_SYNTH: AddNoise -> Bias -> LeakyReLU -> statistics
@@ -53,6 +53,7 @@ struct ConvParams {
     int dbg;                      // diagnostic build only: bit0 = stage pixel 0 everywhere (timing of a cache-resident input)
     int prio;                     // experiment (GSA_PRIO): 1 = the wave OUTSIDE its MFMA phase gets the higher issue priority
     int bf16;                     // 1: bf16 MFMA mode -- wpk/wsc hold bf16 packs [..][tap][kq][16][4], operands rounded at staging
+    const float* zeros;           // >= 64 bytes of zeros in device memory: what conv3x3_wino43's LDS-DMA reads for a pixel outside the image
 };
 
 struct PostParams {

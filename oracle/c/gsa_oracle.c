@@ -300,7 +300,8 @@ static float* pack_wino(const float* w, int O, int I, float std, int use_std, fl
  *                a = fmaf(-4, d2, d4), b = fmaf(-4, d1, d3), c = d4 - d2, e = d3 - d1,
  *                t0 = fmaf(4, d0, fmaf(-5, d2, d4)), t1 = a + b, t2 = a - b, t3 = fmaf(2, e, c), t4 = fmaf(-2, e, c),
  *                t5 = fmaf(4, d1, fmaf(-5, d3, d5));
- *   products   M[f] = one fmaf chain over the input channels per frequency f = 6i+j (block order as everywhere);
+ *   products   M[f] = one fmaf chain over the input channels per frequency f = 6i+j, in the K order of THESE layers: 8-channel
+ *              blocks ascending, inside a block channels 0,2,4,6, 1,3,5,7 (two MFMAs whose k slot kq holds channel 8b + 2kq + j);
  *   output     per 6-vector m (first down the columns of M, then along the rows):
  *                p = m1 + m2, q = m1 - m2, r = m3 + m4, s = m3 - m4,
  *                y0 = (m0 + p) + r, y1 = fmaf(2, s, q), y2 = fmaf(4, r, p), y3 = fmaf(8, s, q) + m5. */
@@ -309,19 +310,18 @@ static float* pack_wino(const float* w, int O, int I, float std, int use_std, fl
 #endif
 static int g_wino43 = -1;
 static int use_wino43(int H, int W, int Cin, int Cout, int bf) {
-    if (g_wino43 < 0) { const char* e = getenv("GSAO_WINO43"); g_wino43 = e ? atoi(e) : 1; }
+    if (g_wino43 < 0) { const char* e = getenv("GSAO_WINO43"); g_wino43 = e ? atoi(e) : 0;      /* opt-in (GSAO_WINO43=1): measured slower than F(2x2,3x3) on MI355X, DESIGN.md section 4 round 4 */ }
     return g_wino43 && use_wino(H, W, Cout, 0, bf) && Cin >= 64 && H >= 32;
 }
 
-/* conv OIHW (O,I,3,3) -> U packed [(cb*36 + f)*CB + c][O], f = 6*i + j */
+/* conv OIHW (O,I,3,3) -> U packed [f*I + c][O], f = 6*i + j */
 static float* pack_wino43(const float* w, int O, int I, float std, int use_std, float lr) {
     static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
     float* out = (float*)malloc(sizeof(float) * (size_t)O * I * 36);
-    for (int cb = 0; cb < I / CB; ++cb)
-        for (int ci = 0; ci < CB; ++ci)
+    for (int ch = 0; ch < I; ++ch)
             for (int o = 0; o < O; ++o) {
-                const float* wk = w + ((size_t)o * I + cb * CB + ci) * 9;
+                const float* wk = w + ((size_t)o * I + ch) * 9;
                 double g[3][3], r[6][3];
                 for (int a = 0; a < 3; ++a)
                     for (int b = 0; b < 3; ++b) g[a][b] = (double)eff(wk[a * 3 + b], std, use_std, lr);
@@ -329,7 +329,7 @@ static float* pack_wino43(const float* w, int O, int I, float std, int use_std, 
                     for (int b = 0; b < 3; ++b) r[i][b] = (G[i][0] * g[0][b] + G[i][1] * g[1][b]) + G[i][2] * g[2][b];
                 for (int i = 0; i < 6; ++i)
                     for (int j = 0; j < 6; ++j)
-                        out[(((size_t)cb * 36 + i * 6 + j) * CB + ci) * O + o] = (float)((r[i][0] * G[j][0] + r[i][1] * G[j][1]) + r[i][2] * G[j][2]);
+                        out[((size_t)(i * 6 + j) * I + ch) * O + o] = (float)((r[i][0] * G[j][0] + r[i][1] * G[j][1]) + r[i][2] * G[j][2]);
             }
     return out;
 }
@@ -380,11 +380,13 @@ static void conv3x3_wino43(const float* in, int H, int W, int Cin, const float* 
                 for (int f = 0; f < 36; ++f) {
                     float acc[OC];
                     for (int o = 0; o < OC; ++o) acc[o] = 0.0f;
-                    for (int cb = 0; cb < Cin / CB; ++cb)
-                        for (int kk = 0; kk < CB; ++kk) {
-                            const int ci = CPERM(kk);
-                            const float a = V[f * Cin + cb * CB + ci];
-                            const float* wrow = U + (((size_t)cb * 36 + f) * CB + ci) * Cout + o0;
+                    /* K order of the F(4x4,3x3) layers: 8-channel blocks ascending; inside a block the two MFMAs j = 0, 1, each a
+                     * k-ordered chain over the k slots kq = 0..3 holding channel 8b + 2kq + j: channels 0,2,4,6, 1,3,5,7 */
+                    for (int cb = 0; cb < Cin / 8; ++cb)
+                        for (int kk = 0; kk < 8; ++kk) {
+                            const int ch = cb * 8 + ((kk & 3) << 1) + (kk >> 2);
+                            const float a = V[f * Cin + ch];
+                            const float* wrow = U + ((size_t)f * Cin + ch) * Cout + o0;
                             for (int o = 0; o < on; ++o) acc[o] = fmaf(a, wrow[o], acc[o]);
                         }
                     for (int o = 0; o < OC; ++o) M[f][o] = acc[o];

@@ -2,6 +2,9 @@
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from gan_segmentation_amd import _lib
+if os.environ.get("GSA_LIB"):
+    _lib.HIP_LIBRARY = os.path.join(os.path.dirname(_lib.HIP_LIBRARY), os.environ["GSA_LIB"])
 from tests.common import gan_setup
 from gan_segmentation_amd.image_generator import ImageGenerator
 from oracle.binding import Oracle
