@@ -786,6 +786,48 @@ def test_cli_generate_stops_at_the_first_bad_batch(torch_cuda, tmp_path, monkeyp
     assert len(list((base / "dataset" / "train_generated").iterdir())) == 24
 
 
+_W43_WORKER = r'''
+import sys
+import numpy as np
+sys.path.insert(0, ROOT_DIR)
+from tests.common import reduced_setup, gan_setup
+from gan_segmentation_amd.image_generator import ImageGenerator
+from oracle.binding import Oracle
+for name, setup in (("reduced", lambda: reduced_setup(7, batch=2, trivial_norm=False)), ("bedrooms", lambda: gan_setup("bedrooms", 2))):
+    gcfg, gp, dcfg, dp, z, noise = setup()
+    gen = ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[0], batch_size=2)
+    rgb, feats, img = gen.netG(z, noise=noise, want_image=True)
+    logits, mask = gen._decoder(*feats, want_mask=True)
+    o = Oracle(gcfg, gp, dcfg, dp)
+    orgb, oimg, ofeats = o.generator(z, noise)
+    ologits, omask = o.decoder(ofeats)
+    for i, (f, of) in enumerate(zip(feats, ofeats)):
+        assert np.array_equal(f.cpu().numpy(), of), "%s feature %d" % (name, i)
+    assert np.array_equal(rgb.cpu().numpy(), orgb) and np.array_equal(img.cpu().numpy(), oimg), name
+    assert np.array_equal(logits.cpu().numpy(), ologits) and np.array_equal(mask.cpu().numpy(), omask), name
+    # the stand-alone decoder (no AdaIN on its inputs: the kernel's no-affine path) on the exported features
+    lg2, mk2 = gen._decoder(*[f.clone() for f in feats], want_mask=True)
+    assert np.array_equal(lg2.cpu().numpy(), ologits), name
+    gen.netG._model.ctx.check()
+print("W43_OK")
+'''
+
+
+def test_winograd_f4x4_form_is_bit_exact_when_selected(torch_cuda, tmp_path):
+    """VERDICT r3 item 4: conv3x3_wino43 -- Winograd F(4x4,3x3) on the matrix cores for the streamed-weight 3x3 layers (36 products
+    per 16 outputs; 8-channel items, both operands by LDS-DMA) -- is OPT-IN (GSA_WINO43=1 with the oracle's GSAO_WINO43=1: it
+    measured 15-20 % slower than F(2x2,3x3), DESIGN.md).  Selected, it reproduces the oracle's F(4x4,3x3) arithmetic bit for
+    bit: reduced 128 px config (g.32.conv_2: every tile an edge tile) and bedrooms 256^2 (conv_2 at 32^2-256^2, decoder cvt at
+    64^2-256^2, interior tiles, both epilogues, the no-AdaIN path) -- reference networks_stylegan.py:354-457."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w43_worker.py"
+    script.write_text(_W43_WORKER.replace("ROOT_DIR", repr(root)))
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, GSA_WINO43="1", GSAO_WINO43="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "W43_OK" in out.stdout, out.stdout[-800:] + out.stderr[-2500:]
+
+
 _SWITCH_WORKER = r'''
 import sys
 sys.path.insert(0, ROOT_DIR)
