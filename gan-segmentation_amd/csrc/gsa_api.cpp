@@ -1063,6 +1063,12 @@ static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, 
                 }
                 snprintf(layer, sizeof layer, "g.%d.post_1", R);
                 Launch lp(c, s, pp.blur ? "post_kernel<blur>" : "post_kernel<const>", layer, 0.0, 4.0 * (2 * px * C + px));
+#ifdef GSA_DBG_HOOKS
+                // diagnostic build only (`make dbg`, GSA_DBG bit 3; WRONG results): leave out the blur / noise / bias / LeakyReLU / statistics
+                // pass of the 512^2 and 1024^2 levels -- what fusing it into the stride-2 convolution could win AT MOST, measured on the
+                // overlapped step rather than priced from the serialized kernel times
+                if (!((c->dbg & 8) && R >= 512))
+#endif
                 HIP_TRY(launch_post(pp, n, s));
                 prow = post_rows_used(pp);
             } else {

@@ -1770,6 +1770,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43(ConvParams p) {
             if (!t.on) return;
             const float* src = p.src0 + ((size_t)((t.n * p.H + t.y0 - 1) * p.W + t.x0 - 1)) * p.C0 + cb * 8;      // halo origin (may lie before the tensor: only masked units use it)
             const float* ptr = (t.mask >> sidx) & 1u ? src + st_rel[sidx] : p.zeros;
+#ifdef GSA_DBG_HOOKS
+            if (p.dbg & 16) ptr = p.src0 + (size_t)((t.n * p.H + t.y0) * p.W) * p.C0 + (sidx * 64 + lane) * 4;      // timing only: a DENSE 1 KB read per instruction (no partial cache lines)
+#endif
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ptr,
                                              (__attribute__((address_space(3))) void*)(sA + buf * IMG + sidx * 256), 16, 0, 0);
         } else {
