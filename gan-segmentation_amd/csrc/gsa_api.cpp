@@ -1095,6 +1095,11 @@ static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, 
             fp.aff = k == 0 ? c->aff1 : c->aff2[l];
             fp.flags = c->map_ctl;      // word 0: statistics range check
             snprintf(layer, sizeof layer, "g.%d.finalize_%d", R, k + 1);
+#ifdef GSA_DBG_HOOKS
+            // diagnostic build only (GSA_DBG bit 5; WRONG results): without the finalize launches a fusion into their small producers would remove
+            if ((c->dbg & 32) && ((k == 0 && R <= 32) || (k == 1 && R <= 8))) continue;
+            if ((c->dbg & 64)) continue;      // bit 6: without ANY finalize launch (the bound of every such fusion)
+#endif
             Launch lp(c, s, "finalize_kernel", layer, 0.0, 16.0 * N * prow * C);
             HIP_TRY(launch_finalize(fp, n, s));
         }

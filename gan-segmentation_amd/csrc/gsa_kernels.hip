@@ -1574,23 +1574,21 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
 //     36 products per 16 outputs (2.25 per output) where F(2x2,3x3) needs 64 (4 per output) and the direct form 144 (9).
 //
 // Thirty-six GEMMs  M_f[cout][tile] = sum_c U_f[c][cout] V_f[tile][c],  f = 6i+j:  the weights are the A operand (M = 16 output
-// channels), the transformed patches the B operand (N = the 16 tiles of a 16x16 output region), K = input channels -- 144 MFMAs
-// per 16-channel block and 256 output pixels where conv3x3_wino issues 256.  Canonical arithmetic: oracle/c/gsa_oracle.c
+// channels), the transformed patches the B operand (N = the 16 tiles of a 16x16 output region), K = input channels -- 72 MFMAs
+// per 8-channel block and 256 output pixels where conv3x3_wino issues 128.  Canonical arithmetic: oracle/c/gsa_oracle.c
 // conv3x3_wino43 (transform op order with its fmaf forms; U = G g G^T in double on the host, rounded once; each M_f one k-ordered
-// fmaf chain = the MFMA): reproduced BIT FOR BIT.  Static rule (layer shape only): conv_uses_wino43.
+// fmaf chain = the MFMA; K order of these layers: 8-channel blocks): reproduced BIT FOR BIT.  Static rule: conv_uses_wino43.
+// OPT-IN (GSA_WINO43=1): measured 15-20 % slower than conv3x3_wino on MI355X -- DESIGN.md section 4 "Round 4" has the five forms
+// this kernel went through, the stamps and the reasons; the body below is the last and fastest of them.
 //
 // One wave = one 16x16 output region; lane (i16, kq) owns tile (ty, tx) = (i16 >> 2, i16 & 3) and k slot kq, and -- weights being
 // the A operand -- leaves the MFMAs with FOUR CONSECUTIVE OUTPUT CHANNELS (4*kq + r) of ITS tile in an accumulator vector: the
 // output transform works on channel vectors, every output pixel is one 16-byte NHWC store, the statistics' x-quads are in-lane.
-// 36 accumulator vectors + 36 patch vectors do not fit two waves per SIMD: the workgroup is FOUR waves, one per SIMD, with the whole
-// register file (launch bound 1) -- what it costs (no second wave to hide a wave's LDS latency) against 1.78x fewer MFMAs is the
-// measurement DESIGN.md reports.
-//   * activation image: WAVE-PRIVATE (18x18 halo pixels x 16 channels, staged by the wave's own lanes as 16-byte chunks with the
-//     AdaIN fma on the way, 21 rounds): no workgroup barrier guards it, only the wave's own LDS counter.  A tile's x stride is
-//     4 pixels = 256 bytes = all 64 banks, so a pixel's four 16-byte chunks are ROTATED by (x >> 2): with the row stride 18*16+4
-//     floats every ds_read_b128 of the 6x6 patch is then bank-conflict free (brute-forced over the ds_read_b128 lane groups);
-//   * weights: the 36 KB panel of (16 couts, 16-channel block) is shared by the four waves, double-buffered in LDS and filled by
-//     LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction, no registers) one item ahead; ONE barrier per item.
+// 36 accumulator vectors (144 registers) do not leave room for two waves per SIMD: the workgroup is FOUR waves, one per SIMD, with
+// the whole register file (launch bound 1); hipcc keeps the accumulators in the accumulation registers and the transforms in the
+// vector registers only when nothing else competes for them, hence NO staging registers: both operands reach LDS by LDS-DMA
+// (global_load_lds_dwordx4, 1 KB per wave-instruction), the image wave-private, the weight panel shared by the four waves, both
+// double-buffered, ONE barrier per item; the next item's DMA is issued between the MFMA groups of the current one.
 // blockIdx.y = output-channel group; a workgroup walks a contiguous (XCD-aware) range of 4-tile items of its group.
 #ifndef GSA_W43_PK
 #define GSA_W43_PK 1
