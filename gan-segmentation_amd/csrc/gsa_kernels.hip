@@ -1117,6 +1117,11 @@ __device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ f32x2 fma2v(f32x2 a, f32x2 m, f32x2 b) {      // fmaf(a, m, b) per component (IEEE fused: the same bits as fmaf)
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(m), "v"(b));
+    return r;
+}
 __device__ __forceinline__ f32x4 add4(const f32x4& a, const f32x4& b) {
     const f32x2 lo = pk_add2(a.xy, b.xy), hi = pk_add2(a.zw, b.zw);
     return f32x4{lo.x, lo.y, hi.x, hi.y};
@@ -1568,6 +1573,266 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
 }
 
 // ------------------------------------------------------------------------------------------
+// conv3x3_wino with ALL staging by LDS-DMA (round 4) -- the streamed-weight layers (>= 64 input channels, one output-channel group
+// per workgroup): same workgroup geometry, same LDS image addresses, same MFMAs, same epilogue, same bits as conv3x3_wino<EPI, 1,
+// true, AFF, 1>; what changes is how the operands reach LDS.  There a thread carries the next-but-one item through 24 + 16
+// prefetch registers (six chunk loads, four weight loads), applies AdaIN and writes LDS (stamps: write ~1600 + load ~1750 of ~8600
+// cycles per item and wave, 256 registers and 20 bytes of scratch); here global_load_lds_dwordx4 moves both operands (21 + 16
+// instructions of 1 KB per item and workgroup), no staging register exists, AdaIN is ONE packed fma per patch vector after the LDS
+// read (the patch of an edge tile masks its zero padding: a pixel outside the image must stay 0, not become B), and the next item's
+// DMA is in flight while this item is multiplied.  MEASURED SLOWER than the register-staged kernel (DESIGN.md section 4, round 4:
+// per item and wave DMA issue ~2400 + barrier ~1800 cycles against write ~1600 + load ~1750 + barrier ~570): opt-in (GSA_WINO_DMA=1).
+// LDS image: the addresses conv3x3_wino reads (row stride 18*16+4 floats = 73 units of 16 bytes); DMA round k of the workgroup fills
+// units 256k .. 256k+255 (wave w: 64 consecutive units), unit u = 73*row + 4*pixel + chunk (u % 73 == 72: the row's padding unit,
+// u >= 1314: the buffer's tail -- both read the page of zeros, as does a pixel outside the image).
+template <int EPI, bool AFF>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_dma(ConvParams p) {
+    constexpr int LH = 18, LW = 18, RS = LW * 16 + 4, RU = RS / 4;          // floats / 16-byte units per image row
+    constexpr int NU = LH * RU, NRD = (NU + 63) / 64;                        // 1314 units, 21 DMA instructions per item
+    constexpr int IMGF = NRD * 256;                                          // floats per image buffer
+    constexpr int SEG = 16 * 256;                                            // U floats per (16 couts, 16-channel block)
+    constexpr int NRT = (NRD + 3) / 4;                                       // DMA rounds per wave (6, the last one for wave 0 only)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nblk = p.C0 >> 4;
+    float* sA = smem;                            // [2][IMGF]
+    float* sB = sA + 2 * IMGF;                   // [2][SEG]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int g = (int)blockIdx.y;
+    const int chunk = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int w_begin = xcd_block(blockIdx.x, gridDim.x) * chunk;
+    const int w_end = min(p.total_tiles, w_begin + chunk);
+    if (w_begin >= w_end) return;
+    struct Tile { int n, y0, x0, row; };
+    auto advance = [&](const Tile& t) {
+        Tile u = t;
+        u.x0 += 16; u.row += 1;
+        if (u.x0 == p.W) { u.x0 = 0; u.y0 += 16; if (u.y0 == p.H) { u.y0 = 0; u.row = 0; u.n += 1; } }
+        return u;
+    };
+    auto is_edge = [&](const Tile& t) { return t.y0 == 0 || t.x0 == 0 || t.y0 + 16 == p.H || t.x0 + 16 == p.W; };
+    // ---- DMA geometry of this thread: round k of its wave fills unit (4k + wave) * 64 + lane
+    int st_rel[NRT];                             // float offset of the unit's source from the halo origin
+    int st_yx[NRT];                              // (ly << 8) | lx, or -1: no pixel behind this unit
+#pragma unroll
+    for (int k = 0; k < NRT; ++k) {
+        const int u = (4 * k + wave) * 64 + lane, ly = u / RU, w = u - ly * RU, lx = w >> 2, ch = w & 3;
+        const bool valid = u < NU && w < 72;
+        st_yx[k] = valid ? (ly << 8) | lx : -1;
+        st_rel[k] = valid ? (ly * p.W + lx) * p.C0 + ch * 4 : 0;
+    }
+    auto tile_mask = [&](const Tile& t) {        // bit k: the unit of round k is a pixel inside the image
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < NRT; ++k) {
+            const int ly = st_yx[k] >> 8, lx = st_yx[k] & 0xff;
+            if (st_yx[k] >= 0 && (unsigned)(t.y0 + ly - 1) < (unsigned)p.H && (unsigned)(t.x0 + lx - 1) < (unsigned)p.W) m |= 1u << k;
+        }
+        return m;
+    };
+    const float* wgrp = p.wpk + (size_t)g * nblk * SEG;
+    auto dma_item = [&](const Tile& t, unsigned mask, int cb, int buf) {
+        const float* src = p.src0 + ((size_t)((t.n * p.H + t.y0 - 1) * p.W + t.x0 - 1)) * p.C0 + cb * 16;      // halo origin (only masked units use it)
+#pragma unroll
+        for (int k = 0; k < NRT; ++k) {
+            if (4 * k + wave < NRD) {            // wave-uniform
+                const float* ptr = (mask >> k) & 1u ? src + st_rel[k] : p.zeros;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ptr,
+                                                 (__attribute__((address_space(3))) void*)(sA + buf * IMGF + (4 * k + wave) * 256), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {            // the item's 16 KB weight block: 16 pieces, four per wave
+            const int piece = wave + 4 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wgrp + (size_t)cb * SEG + piece * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(sB + buf * SEG + piece * 256), 16, 0, 0);
+        }
+    };
+    // A operand: the 4x4 input patch of this lane's Winograd tile (halo coordinates), k slot kq -- as in conv3x3_wino
+    const int wty = ((i16 >> 3) & 1) * 2 + ((i16 >> 1) & 1), wtx = ((i16 >> 2) & 1) * 2 + (i16 & 1);
+    const int prow = (wave >> 1) * 8 + 2 * wty, pcol = (wave & 1) * 8 + 2 * wtx;      // halo row / column of the patch origin
+    const int pbase = prow * RS + pcol * 16 + kq * 4;
+    const int bbase = (kq * 16 + i16) * 4;
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- epilogue geometry and code: conv3x3_wino's, NT = 1
+    const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;
+    const int prow0 = (wave >> 1) * 8 + ((lane >> 5) & 1) * 4, pcol0 = (wave & 1) * 8 + ((lane >> 4) & 1) * 4;
+    const int co0 = g * 16;
+    const unsigned lane_out = (unsigned)((prow0 * p.W + pcol0 + xj) * p.Cout + co0 + cq4);
+    const unsigned lane_nz = (unsigned)(prow0 * p.W + pcol0);
+    float4 nzs[EPI == EPI_SYNTH ? 4 : 1];
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+    if (EPI == EPI_SYNTH) { e0 = p.nscale[co0 + i16]; e1 = p.nbias[co0 + i16]; }
+    if (EPI == EPI_DEC) { e2 = p.bn_s[co0 + i16]; e3 = p.bn_beta[co0 + i16]; }
+    auto epilogue_loads = [&](const Tile& tc) {
+        if (EPI == EPI_SYNTH) {
+            const float* nz = p.noise + ((size_t)(tc.n * p.H + tc.y0) * p.W + tc.x0) + lane_nz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nzs[r] = *reinterpret_cast<const float4*>(nz + r * p.W);
+        }
+    };
+    const int s2 = stat_s2(p.H * p.W);
+    unsigned long long dI1 = 0ull, dI2 = 0ull;
+    auto flush_stats = [&](const Tile& t) {
+        unsigned long long I1 = dI1, I2 = dI2;
+        I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
+        I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
+        if (lane < 16) {
+            StatPart* a = p.partials + ((size_t)t.n * p.prow + (blockIdx.x & (kDirectRows - 1))) * p.Cout + co0 + i16;
+            atomicAdd(&a->s1, I1);
+            atomicAdd(&a->s2, I2);
+        }
+        dI1 = dI2 = 0ull;
+    };
+    auto epilogue = [&](const Tile& tc) {
+        const size_t ubase = ((size_t)(tc.n * p.H + tc.y0) * p.W + tc.x0) * p.Cout;
+        f32x4 s0[4], s1[4], m[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) m[f] = acc[f];
+        mfma_settle(m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = add4(add4(m[j], m[4 + j]), m[8 + j]);
+            s1[j] = sub4(sub4(m[4 + j], m[8 + j]), m[12 + j]);
+        }
+        const f32x4 y00 = add4(add4(s0[0], s0[1]), s0[2]), y01 = sub4(sub4(s0[1], s0[2]), s0[3]);
+        const f32x4 y10 = add4(add4(s1[0], s1[1]), s1[2]), y11 = sub4(sub4(s1[1], s1[2]), s1[3]);
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b1 = r >> 1;
+            const f32x4& ya = (r & 1) ? y10 : y00;
+            const f32x4& yb = (r & 1) ? y11 : y01;
+            float v[4] = {ya[2 * b1], yb[2 * b1], ya[2 * b1 + 1], yb[2 * b1 + 1]};
+            if (EPI == EPI_SYNTH) {
+                const float nzv[4] = {nzs[r].x, nzs[r].y, nzs[r].z, nzs[r].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = e0 * nzv[k];
+                    v[k] = lrelu((v[k] + t) + e1);
+                }
+                const float sq = (v[0] + v[1]) + (v[2] + v[3]);
+                const float qq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                dI1 += to_fixed(sq, kStatScale1);
+                dI2 += to_fixed_sq(qq, s2);
+            }
+            if (EPI == EPI_DEC) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = lrelu(fmaf(v[k], e2, e3));
+            }
+            const f32x4 vt = quad_transpose(v[0], v[1], v[2], v[3], xj);
+            *reinterpret_cast<f32x4*>(p.out + ubase + (size_t)r * p.W * p.Cout + lane_out) = vt;
+        }
+    };
+
+    auto wino_item = [&](auto edge_tag, int buf, const f32x4& cA, const f32x4& cB, unsigned rowin, unsigned colin) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        __builtin_amdgcn_s_setprio(GSA_MFMA_PRIO);
+        const float* a_img = sA + buf * IMGF + pbase;
+        const float* b_img = sB + buf * SEG + bbase;
+        f32x4 V[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 d[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d[r] = *reinterpret_cast<const f32x4*>(a_img + r * RS + c * 16);
+                if (AFF) {                       // AdaIN: fmaf(x, A, B) on the lane's four channels -- what the staging did before the LDS write
+                    const f32x2 lo = fma2v(d[r].xy, cA.xy, cB.xy), hi = fma2v(d[r].zw, cA.zw, cB.zw);
+                    d[r] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                    if (EDGE) { if (!((rowin >> r) & (colin >> c) & 1u)) d[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }      // zero padding stays zero
+                }
+            }
+            V[0 * 4 + c] = sub4(d[0], d[2]);
+            V[1 * 4 + c] = add4(d[1], d[2]);
+            V[2 * 4 + c] = sub4(d[2], d[1]);
+            V[3 * 4 + c] = sub4(d[1], d[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 t0 = V[i * 4 + 0], t1 = V[i * 4 + 1], t2 = V[i * 4 + 2], t3 = V[i * 4 + 3];
+            V[i * 4 + 0] = sub4(t0, t2);
+            V[i * 4 + 1] = add4(t1, t2);
+            V[i * 4 + 2] = sub4(t2, t1);
+            V[i * 4 + 3] = sub4(t1, t3);
+            valu_settle(V[i * 4 + 0], V[i * 4 + 1], V[i * 4 + 2], V[i * 4 + 3]);
+        }
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            f32x4 b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_img + (fb * 4 + j) * 256);
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[fb * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[fb * 4 + j][cg], b[j][cg], acc[fb * 4 + j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- items (tile, channel block): item `it` is multiplied out of buffer it & 1 while the DMA of item it+1 fills the other
+    const int total_items = (w_end - w_begin) * nblk;
+    Tile tc;
+    {
+        const int tx = w_begin % p.tiles_x, r = w_begin / p.tiles_x;
+        tc.x0 = tx * 16; tc.y0 = (r % p.tiles_y) * 16; tc.n = r / p.tiles_y; tc.row = (r % p.tiles_y) * p.tiles_x + tx;
+    }
+    int cb = 0;
+    unsigned mask_c = tile_mask(tc);
+    dma_item(tc, mask_c, 0, 0);
+    unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, sl = 0, sm = 0, se = 0, sb = 0;
+    (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)sl; (void)sm; (void)se; (void)sb;
+    for (int it = 0; it < total_items; ++it) {
+        TICK(k0);
+        const bool has_next = it + 1 < total_items;
+        // AdaIN coefficients of the lane's four channels 16cb + 4kq .. +3 (tiny, L2-resident; issued before the barrier's wait)
+        f32x4 cA = f32x4{1.f, 1.f, 1.f, 1.f}, cB = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned rowin = 0xf, colin = 0xf;
+        if (AFF) {
+            const f32x4* ap = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)tc.n * p.C0 + cb * 16 + kq * 4);
+            const f32x4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+            cA = f32x4{a0[1], a1[1], a2[1], a3[1]};
+            cB = f32x4{a0[2], a1[2], a2[2], a3[2]};
+        }
+        const bool edge = is_edge(tc);
+        if (AFF && edge) {
+            rowin = 0; colin = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if ((unsigned)(tc.y0 + prow + r - 1) < (unsigned)p.H) rowin |= 1u << r;
+                if ((unsigned)(tc.x0 + pcol + r - 1) < (unsigned)p.W) colin |= 1u << r;
+            }
+        }
+        __syncthreads();                         // item `it` has landed; every wave has left the buffer the next DMA overwrites
+        TICK(k1);
+        Tile tn = tc; int cbn = cb + 1; unsigned mask_n = mask_c;
+        if (cbn == nblk) { cbn = 0; if (has_next) { tn = advance(tc); mask_n = tile_mask(tn); } }
+        if (has_next) dma_item(tn, mask_n, cbn, (it + 1) & 1);
+        if (cb == nblk - 1) epilogue_loads(tc);
+        TICK(k2);
+        if (AFF && edge) wino_item(std::true_type{}, it & 1, cA, cB, rowin, colin);
+        else wino_item(std::false_type{}, it & 1, cA, cB, rowin, colin);
+        TICK(k3);
+        if (cb == nblk - 1) {
+            epilogue(tc);
+            if (EPI == EPI_SYNTH && (!has_next || tn.n != tc.n)) flush_stats(tc);
+        }
+        TICK(k4);
+        TSUM(sb, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4);
+        tc = tn; cb = cbn; mask_c = mask_n;
+    }
+    TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(9, se); TFLUSH(10, sb);
+    TFLUSH(12, (unsigned long long)total_items); TFLUSH(15, 1ull);
+}
+
+// ------------------------------------------------------------------------------------------
 // conv3x3 (pad 1, stride 1, one source) in WINOGRAD F(4x4, 3x3) form on v_mfma_f32_16x16x4_f32 (round 4).
 //
 //     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A      per 4x4 OUTPUT tile from its 6x6 input patch:
@@ -1605,15 +1870,6 @@ __device__ __forceinline__ f32x2 fma2c(float c, f32x2 a, f32x2 b) {
     return pk_fma2s(a, f32x2{c, c}, b);
 #else
     return f32x2{fmaf(c, a.x, b.x), fmaf(c, a.y, b.y)};
-#endif
-}
-__device__ __forceinline__ f32x2 fma2v(f32x2 a, f32x2 m, f32x2 b) {      // fmaf(a, m, b) per component
-#if GSA_W43_PK
-    f32x2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(m), "v"(b));
-    return r;
-#else
-    return f32x2{fmaf(a.x, m.x, b.x), fmaf(a.y, m.y, b.y)};
 #endif
 }
 __device__ __forceinline__ f32x2 add2c(f32x2 a, f32x2 b) {
@@ -3903,7 +4159,51 @@ static int wino_gw(const ConvParams& p) {
     return (forced >= 2 || p.C0 <= 32) ? 2 : 1;
 }
 
+// conv3x3_wino_dma: the streamed-weight layers (>= 64 input channels) with every operand staged by LDS-DMA.  Speed only -- the same
+// arithmetic as conv3x3_wino, same bits -- and measured 8-10 % SLOWER (g.64.conv_2 0.250 vs 0.227 ms: ~260 cycles per DMA instruction
+// with eight waves per CU, and every wave waits at the barrier for the slowest wave's DMA): opt-in, GSA_WINO_DMA=1, for A/B runs.
+static bool wino_dma(const ConvParams& p, int epi) {
+    static const bool enabled = getenv("GSA_WINO_DMA") && atoi(getenv("GSA_WINO_DMA")) != 0;
+    return enabled && p.C0 >= 64 && p.zeros != nullptr && p.resid == nullptr && (epi == EPI_SYNTH ? p.partials != nullptr : true);
+}
+
+template <int EPI, bool AFF>
+static hipError_t launch_wino_dma_t(const ConvParams& p, int n, hipStream_t s) {
+    constexpr int IMGF = 21 * 256, SEG = 16 * 256;
+    const size_t lds = sizeof(float) * (2 * IMGF + 2 * SEG);
+    auto kern = conv3x3_wino_dma<EPI, AFF>;
+    if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
+    static LaunchState states[kMaxDevices];
+    int num_cus = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_launch_mu);
+        hipError_t e = prepare_kernel(kern, states[p.device]);
+        if (e != hipSuccess) return e;
+        num_cus = device_cus(p.device);
+    }
+    ConvParams q = p;
+    q.wpk = p.wino;
+    q.tiles_x = p.W / 16;
+    q.tiles_y = p.H / 16;
+    q.groups = p.Cout / 16;
+    q.total_tiles = q.tiles_x * q.tiles_y * n;
+    // persistent workgroups, two per CU, each inside its channel group; (x, g) -> linear index x + g * gx: the groups of a tile range share an XCD's L2
+    const int slots = std::max(1, num_cus * 2 / q.groups);
+    const int gx = std::min(q.total_tiles, slots);
+    q.stats_direct = 1;
+    q.prow = kDirectRows;
+    if (p.stat_rows_host) *p.stat_rows_host = q.prow;
+    hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256), lds, s, q);
+    return hipGetLastError();
+}
+
+static hipError_t launch_wino_dma(const ConvParams& p, int epi, int n, hipStream_t s) {
+    if (epi == EPI_SYNTH) return p.aff0 ? launch_wino_dma_t<EPI_SYNTH, true>(p, n, s) : launch_wino_dma_t<EPI_SYNTH, false>(p, n, s);
+    return p.aff0 ? launch_wino_dma_t<EPI_DEC, true>(p, n, s) : launch_wino_dma_t<EPI_DEC, false>(p, n, s);
+}
+
 static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s) {
+    if (wino_dma(p, epi) && wino_nt(p) == 1) return launch_wino_dma(p, epi, n, s);
     const int nt = wino_nt(p);
     const int gw = wino_gw(p);
     const bool ch = wino_chunk(p);
@@ -3925,6 +4225,10 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     static thread_local char buf[128];
     if (conv_uses_wino43(p, epi, sc)) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_wino43<%d>(gsa::ConvParams)", epi);
+        return buf;
+    }
+    if (conv_uses_wino(p, epi, sc) && wino_dma(p, epi) && wino_nt(p) == 1) {
+        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino_dma<%d, %s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false");
         return buf;
     }
     if (conv_uses_wino(p, epi, sc)) {
