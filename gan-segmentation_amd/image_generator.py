@@ -286,11 +286,18 @@ class ImageGenerator:
         k = self.__dict__["_status_next"]
         self.__dict__["_status_next"] = (k + 1) % 32
         views = []
+        dev0 = self._gens[0]._model.device
         for g, slots in zip(self._gens, ring):
             dev = g._model.device
             view = slots[k]
             with torch.cuda.device(dev):
                 g._model.ctx.status_snapshot(current_stream_ptr(dev), view.data_ptr())
+                if dev != dev0:
+                    # the reader synchronises with the FIRST device's stream (where the collected pairs live): make that stream
+                    # wait for this replica's copy too, or the slot could be read before it has landed
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    torch.cuda.current_stream(dev0).wait_event(ev)
             views.append(view)
         return views
 
