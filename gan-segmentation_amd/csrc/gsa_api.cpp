@@ -1062,6 +1062,17 @@ static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, 
                     pp.src = c->t_raw; pp.src_per_sample = 1; pp.blur = B.blur;
                 }
                 snprintf(layer, sizeof layer, "g.%d.post_1", R);
+                if (post_fuses_finalize(pp)) {       // small plane: post pass + finalize in ONE launch (the workgroup holds the whole plane)
+                    FinalizeParams fp{};
+                    fp.partials = c->partials; fp.prow = 0; fp.HW = R * R; fp.C = C; fp.acc = c->stat_acc; fp.tickets = c->stat_tickets;
+                    fp.style = c->styles + B.style_off[0]; fp.style_stride = c->style_cols;
+                    fp.gamma = B.gamma[0]; fp.beta = B.beta[0];
+                    fp.aff = c->aff1;
+                    fp.flags = c->map_ctl;
+                    Launch lp(c, s, pp.blur ? "post_fin_kernel<blur>" : "post_fin_kernel<const>", layer, 0.0, 4.0 * (2 * px * C + px));
+                    HIP_TRY(launch_post_fin(pp, fp, n, s));
+                    continue;
+                }
                 Launch lp(c, s, pp.blur ? "post_kernel<blur>" : "post_kernel<const>", layer, 0.0, 4.0 * (2 * px * C + px));
 #ifdef GSA_DBG_HOOKS
                 // diagnostic build only (`make dbg`, GSA_DBG bit 3; WRONG results): leave out the blur / noise / bias / LeakyReLU / statistics

@@ -88,6 +88,8 @@ hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, h
 bool subpixel_uses_wino(const ConvParams& p);                      // true: Winograd F(2x2,2x2) form (static rule: fp32 mode): 9 products per 2x2 class outputs instead of 163x3
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s);
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);
+bool post_fuses_finalize(const PostParams& p);      // true: launch_post_fin does the post pass AND the finalize of this plane in one launch (planes <= 32 x 32)
+hipError_t launch_post_fin(const PostParams& p, const FinalizeParams& f, int n, hipStream_t s);
 hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_t s);
 // PixelNorm + the eight mapping layers in one launch (result in lat[0]); mapping_fused: whether it applies to this latent size
 constexpr int kMapSlices = 8;     // most sample slices of the fused mapping network (launch-number words ctl[2 .. 2 + kMapSlices))

@@ -2928,6 +2928,74 @@ __global__ __launch_bounds__(512, 2) void subpixel_res(ConvParams p) {
 // ------------------------------------------------------------------------------------------
 // Blur (depthwise 3x3, zero pad) -> AddNoise -> Bias -> LeakyReLU -> statistics.
 // One thread = one aligned quad of 4 consecutive x for 4 consecutive channels.
+// One element of the post pass -- blur (or the constant tensor), noise, bias, LeakyReLU for 4 consecutive x and 4 channels at (n, y, x0, c) --
+// stored to p.out and returned in v[x][channel] for the statistics (post_kernel and post_fin_kernel share it: same operations, same bits)
+template <bool BF>
+__device__ __forceinline__ void post_element(const PostParams& p, int n, int c, int x0, int y, float (&v)[4][4]) {
+            // per-sample source = an activation tensor (bf16 in bf16 mode); the broadcast constant tensor is an fp32 parameter
+            const size_t sbase = p.src_per_sample ? (size_t)n * p.H * p.W * p.C : 0;
+                    if (p.blur) {
+                float wk[4][9];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                    for (int t = 0; t < 9; ++t) wk[j][t] = p.blur[(c + j) * 9 + t];
+    #pragma unroll
+                for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) v[r][j] = 0.0f;
+                // all 18 loads are unconditional (clamped coordinates) and issued before the first use; taps outside the
+                // image are zeroed values: fmaf(0, w, b) == b bit for bit (b is never -0), i.e. the same as skipping them
+                float4 row[3][6];
+    #pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = y + ky - 1;
+                    const bool vy = yy >= 0 && yy < p.H;
+                    const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+    #pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int xx = x0 - 1 + k;
+                        const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+                        const f32x4 ld = act_load4<BF>(p.src, sbase + ((size_t)yc * p.W + xc) * p.C + c);
+                        row[ky][k] = make_float4(ld[0], ld[1], ld[2], ld[3]);
+                        if (!(vy && xx >= 0 && xx < p.W)) row[ky][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+    #pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float4 t = row[ky][r + kx];
+                            v[r][0] = fmaf(t.x, wk[0][ky * 3 + kx], v[r][0]);
+                            v[r][1] = fmaf(t.y, wk[1][ky * 3 + kx], v[r][1]);
+                            v[r][2] = fmaf(t.z, wk[2][ky * 3 + kx], v[r][2]);
+                            v[r][3] = fmaf(t.w, wk[3][ky * 3 + kx], v[r][3]);
+                        }
+            } else {
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 t = *reinterpret_cast<const float4*>(p.src + sbase + ((size_t)y * p.W + x0 + r) * p.C + c);      // no blur: the fp32 constant tensor
+                    v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+                }
+            }
+            const float4 nz = *reinterpret_cast<const float4*>(p.noise + ((size_t)n * p.H + y) * p.W + x0);
+            const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
+            const float4 sf = *reinterpret_cast<const float4*>(p.nscale + c);
+            const float4 nb = *reinterpret_cast<const float4*>(p.nbias + c);
+            const float sfv[4] = {sf.x, sf.y, sf.z, sf.w}, nbv[4] = {nb.x, nb.y, nb.z, nb.w};
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = sfv[j] * nzv[r];
+                    v[r][j] = lrelu((v[r][j] + t) + nbv[j]);
+                }
+                act_store4<BF>(p.out, (((size_t)n * p.H + y) * p.W + x0 + r) * p.C + c, f32x4{v[r][0], v[r][1], v[r][2], v[r][3]});
+            }
+}
+
 template <bool BF>
 __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sstat[];   // [2][C]
@@ -2945,69 +3013,8 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
         const int cq = idx % C4, t = idx / C4;
         const int xq = (t / bh) % W4, y = (t / (bh * W4)) * bh + t % bh;
         const int c = cq * 4, x0 = xq * 4;
-        // per-sample source = an activation tensor (bf16 in bf16 mode); the broadcast constant tensor is an fp32 parameter
-        const size_t sbase = p.src_per_sample ? (size_t)n * p.H * p.W * p.C : 0;
         float v[4][4];   // [x][channel]
-        if (p.blur) {
-            float wk[4][9];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < 9; ++t) wk[j][t] = p.blur[(c + j) * 9 + t];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[r][j] = 0.0f;
-            // all 18 loads are unconditional (clamped coordinates) and issued before the first use; taps outside the
-            // image are zeroed values: fmaf(0, w, b) == b bit for bit (b is never -0), i.e. the same as skipping them
-            float4 row[3][6];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = y + ky - 1;
-                const bool vy = yy >= 0 && yy < p.H;
-                const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const int xx = x0 - 1 + k;
-                    const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
-                    const f32x4 ld = act_load4<BF>(p.src, sbase + ((size_t)yc * p.W + xc) * p.C + c);
-                    row[ky][k] = make_float4(ld[0], ld[1], ld[2], ld[3]);
-                    if (!(vy && xx >= 0 && xx < p.W)) row[ky][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float4 t = row[ky][r + kx];
-                        v[r][0] = fmaf(t.x, wk[0][ky * 3 + kx], v[r][0]);
-                        v[r][1] = fmaf(t.y, wk[1][ky * 3 + kx], v[r][1]);
-                        v[r][2] = fmaf(t.z, wk[2][ky * 3 + kx], v[r][2]);
-                        v[r][3] = fmaf(t.w, wk[3][ky * 3 + kx], v[r][3]);
-                    }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float4 t = *reinterpret_cast<const float4*>(p.src + sbase + ((size_t)y * p.W + x0 + r) * p.C + c);      // no blur: the fp32 constant tensor
-                v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
-            }
-        }
-        const float4 nz = *reinterpret_cast<const float4*>(p.noise + ((size_t)n * p.H + y) * p.W + x0);
-        const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
-        const float4 sf = *reinterpret_cast<const float4*>(p.nscale + c);
-        const float4 nb = *reinterpret_cast<const float4*>(p.nbias + c);
-        const float sfv[4] = {sf.x, sf.y, sf.z, sf.w}, nbv[4] = {nb.x, nb.y, nb.z, nb.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float t = sfv[j] * nzv[r];
-                v[r][j] = lrelu((v[r][j] + t) + nbv[j]);
-            }
-            act_store4<BF>(p.out, (((size_t)n * p.H + y) * p.W + x0 + r) * p.C + c, f32x4{v[r][0], v[r][1], v[r][2], v[r][3]});
-        }
+        post_element<BF>(p, n, c, x0, y, v);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float s = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
@@ -3158,6 +3165,34 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
 // folds InstanceNorm(eps 1e-5) with the style and clears acc and the ticket for the next layer.
 // Hand-off between blocks: device-scope atomics on both sides (the adds, the ticket, and the
 // final reads via atomic exchange), never plain loads of another block's data.
+// InstanceNorm + AdaIN coefficients of channel c of sample n from its two fixed-point sums (the tail of finalize_kernel; also called by
+// the producers that hold a whole plane in one workgroup: post_fin_kernel)
+__device__ __forceinline__ void finalize_one(const FinalizeParams& p, int n, int c, unsigned long long I1, unsigned long long I2) {
+    const double inv_hw = 1.0 / (double)p.HW;   // HW is a power of two
+    const double m = (double)(long long)I1 * (1.0 / kStatScale1) * inv_hw;
+    const double e2 = (double)(long long)I2 * (1.0 / stat_scale2(p.HW)) * inv_hw;
+    double var = fma(-m, m, e2);
+    // range check of the fixed-point sums (include/gsa.h): a sum within a factor 4 of the 64-bit wrap, or a variance that is
+    // negative beyond rounding (what a wrapped sum of squares produces), sets the sticky word gsa_check reports
+    {
+        const long long s1 = (long long)I1;
+        const bool near_wrap = (s1 < 0 ? -s1 : s1) >= (1ll << 61) || I2 >= (1ull << 61);
+        if (p.flags && (near_wrap || var < -1e-6 * (e2 + m * m) - 1e-30)) atomicOr(p.flags, 1u);
+    }
+    if (!(var > 0.0)) var = 0.0;
+    const float mean_f = (float)m, var_f = (float)var;
+    const float inv = 1.0f / sqrtf(var_f + 1e-5f);
+    const float gsc = p.gamma[c] * inv;
+    const float* st = p.style + (size_t)n * p.style_stride;
+    const float s1 = st[c] + 1.0f;
+    Aff a;
+    a.mean = mean_f;
+    a.A = gsc * s1;
+    a.B = fmaf(-mean_f, a.A, fmaf(p.beta[c], s1, st[p.C + c]));      // the mean folded into the shift: consumers apply ONE fmaf(x, A, B)
+    a.pad = 0.0f;
+    p.aff[(size_t)n * p.C + c] = a;
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p, int rows_per_block) {
     __shared__ unsigned long long sh[2][256];
     __shared__ int is_last;
@@ -3210,30 +3245,37 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p, int row
             I1 = atomicExch(&ap->s1, 0ull);      // read the total and clear it for the next layer
             I2 = atomicExch(&ap->s2, 0ull);
         }
-        const double inv_hw = 1.0 / (double)p.HW;   // HW is a power of two
-        const double m = (double)(long long)I1 * (1.0 / kStatScale1) * inv_hw;
-        const double e2 = (double)(long long)I2 * (1.0 / stat_scale2(p.HW)) * inv_hw;
-        double var = fma(-m, m, e2);
-        // range check of the fixed-point sums (include/gsa.h): a sum within a factor 4 of the 64-bit wrap, or a variance that is
-        // negative beyond rounding (what a wrapped sum of squares produces), sets the sticky word gsa_check reports
-        {
-            const long long s1 = (long long)I1;
-            const bool near_wrap = (s1 < 0 ? -s1 : s1) >= (1ll << 61) || I2 >= (1ull << 61);
-            if (p.flags && (near_wrap || var < -1e-6 * (e2 + m * m) - 1e-30)) atomicOr(p.flags, 1u);
-        }
-        if (!(var > 0.0)) var = 0.0;
-        const float mean_f = (float)m, var_f = (float)var;
-        const float inv = 1.0f / sqrtf(var_f + 1e-5f);
-        const float gsc = p.gamma[c] * inv;
-        const float* st = p.style + (size_t)n * p.style_stride;
-        const float s1 = st[c] + 1.0f;
-        Aff a;
-        a.mean = mean_f;
-        a.A = gsc * s1;
-        a.B = fmaf(-mean_f, a.A, fmaf(p.beta[c], s1, st[p.C + c]));      // the mean folded into the shift: consumers apply ONE fmaf(x, A, B)
-        a.pad = 0.0f;
-        p.aff[(size_t)n * p.C + c] = a;
+        finalize_one(p, n, c, I1, I2);
     }
+}
+
+// Post pass AND finalize in one launch for small planes (round 4): one workgroup = one (sample, 16-channel group) plane, so its LDS
+// sums are the plane's complete statistics and the coefficients follow at once -- no partial rows, no finalize launch.  Where the
+// small launches are the critical path (bf16 mode, small batches: a finalize launch costs ~7 us between two kernel boundaries) this
+// removes one launch per level up to 32 px; the large-batch fp32 step hides them anyway.  Same bits:
+// integer sums, the same finalize_one.
+template <bool BF>
+__global__ __launch_bounds__(256) void post_fin_kernel(PostParams p, FinalizeParams f) {
+    __shared__ unsigned long long sstat[2][16];
+    const int n = blockIdx.y, c0 = blockIdx.x * 16;
+    const int W4 = p.W >> 2, total = p.H * W4 * 4;
+    if (threadIdx.x < 32) sstat[threadIdx.x >> 4][threadIdx.x & 15] = 0ull;
+    __syncthreads();
+    const int s2 = stat_s2(p.H * p.W);
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int cq = e & 3, t = e >> 2, xq = t % W4, y = t / W4;
+        float v[4][4];
+        post_element<BF>(p, n, c0 + cq * 4, xq * 4, y, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
+            const float q = (v[0][j] * v[0][j] + v[1][j] * v[1][j]) + (v[2][j] * v[2][j] + v[3][j] * v[3][j]);
+            atomicAdd(&sstat[0][cq * 4 + j], to_fixed(s, kStatScale1));
+            atomicAdd(&sstat[1][cq * 4 + j], to_fixed_sq(q, s2));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) finalize_one(f, n, c0 + threadIdx.x, sstat[0][threadIdx.x], sstat[1][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4521,6 +4563,19 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
     else hipLaunchKernelGGL(post_kernel<BF>, grid, dim3(256), lds, s, q);
     if (p.bf16) { GSA_POST(true) } else { GSA_POST(false) }
 #undef GSA_POST
+    return hipGetLastError();
+}
+
+// post_fin_kernel: planes of at most 32 x 32 pixels with a multiple of 16 channels (GSA_FUSEFIN=0: the two separate launches)
+bool post_fuses_finalize(const PostParams& p) {
+    static const bool enabled = !(getenv("GSA_FUSEFIN") && atoi(getenv("GSA_FUSEFIN")) == 0);
+    return enabled && p.H * p.W <= 1024 && p.C % 16 == 0 && p.W % 4 == 0;
+}
+hipError_t launch_post_fin(const PostParams& p, const FinalizeParams& f, int n, hipStream_t s) {
+    if (!post_fuses_finalize(p)) return hipErrorInvalidValue;
+    dim3 grid(p.C / 16, n);
+    if (p.bf16) hipLaunchKernelGGL(post_fin_kernel<true>, grid, dim3(256), 0, s, p, f);
+    else hipLaunchKernelGGL(post_fin_kernel<false>, grid, dim3(256), 0, s, p, f);
     return hipGetLastError();
 }
 
