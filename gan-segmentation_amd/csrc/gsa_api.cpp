@@ -1091,11 +1091,18 @@ static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, 
                 snprintf(layer, sizeof layer, "g.%d.conv_2", R);
                 int rows = conv_stat_rows(R, R, C, n);
                 cp.stat_rows_host = &rows;            // the launcher reports the partial rows it used
+                const bool fused_fin = conv_fuses_finalize(cp, EPI_SYNTH, false);
+                if (fused_fin) {                      // the workgroup holds the whole plane: it writes the coefficients itself, no finalize launch
+                    cp.fin_style = c->styles + B.style_off[1]; cp.fin_style_stride = c->style_cols;
+                    cp.fin_gamma = B.gamma[1]; cp.fin_beta = B.beta[1]; cp.fin_aff = c->aff2[l]; cp.fin_flags = c->map_ctl;
+                }
                 Launch lp(c, s, conv_kernel_name(cp, n, EPI_SYNTH, false), layer, 2.0 * px * C * C * (conv_uses_wino43(cp, EPI_SYNTH, false) ? 2.25 : conv_uses_wino(cp, EPI_SYNTH, false) ? 4 : 9), 4.0 * (2 * px * C + px), 2.0 * px * C * C * 9);
                 HIP_TRY(launch_conv3x3(cp, EPI_SYNTH, false, n, s));
                 prow = rows;
+                if (fused_fin) continue;
             }
-            if (c->fault == 2 && l == 1 && k == 1) {      // fault injection (tests): ONE pass dies between a producer and its finalize
+            if (c->fault == 2 && l == 3 && k == 1) {      // fault injection (tests): ONE pass dies between a producer and its finalize (32 px conv_2: a level whose
+                                                          // statistics still travel through partial rows -- the 4 / 8 px layers finalize in their producer)
                 c->fault = 0;
                 return fail(c, GSA_ERR_HIP, "injected fault (gsa_debug_inject 2) between a statistics producer and its finalize");
             }

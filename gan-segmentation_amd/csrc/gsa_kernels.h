@@ -53,6 +53,9 @@ struct ConvParams {
     int dbg;                      // diagnostic build only: bit0 = stage pixel 0 everywhere (timing of a cache-resident input)
     int prio;                     // experiment (GSA_PRIO): 1 = the wave OUTSIDE its MFMA phase gets the higher issue priority
     int bf16;                     // 1: bf16 MFMA mode -- wpk/wsc hold bf16 packs [..][tap][kq][16][4], operands rounded at staging
+    // EPI_SYNTH in a kernel whose workgroup holds a WHOLE plane (conv3x3_ksplit at 4 and 8 px: conv_fuses_finalize): the workgroup writes
+    // the AdaIN coefficients itself instead of partial rows -- the finalize launch of the layer is skipped (fin_aff null: not fused)
+    const float* fin_style; int fin_style_stride; const float* fin_gamma; const float* fin_beta; Aff* fin_aff; unsigned* fin_flags;
     const float* zeros;           // >= 64 bytes of zeros in device memory: what conv3x3_wino43's LDS-DMA reads for a pixel outside the image
 };
 
@@ -88,6 +91,7 @@ hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, h
 bool subpixel_uses_wino(const ConvParams& p);                      // true: Winograd F(2x2,2x2) form (static rule: fp32 mode): 9 products per 2x2 class outputs instead of 163x3
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s);
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);
+bool conv_fuses_finalize(const ConvParams& p, int epi, bool shortcut);   // true: launch_conv3x3 writes the layer's AdaIN coefficients itself when p.fin_aff is set (whole-plane K-split tiles)
 bool post_fuses_finalize(const PostParams& p);      // true: launch_post_fin does the post pass AND the finalize of this plane in one launch (planes <= 32 x 32)
 hipError_t launch_post_fin(const PostParams& p, const FinalizeParams& f, int n, hipStream_t s);
 hipError_t launch_pixelnorm(const float* z, float* out, int n, int L, hipStream_t s);

@@ -914,6 +914,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_mfma(ConvParams p) {
 // PS = 2 (8x8 tiles): EIGHT waves -- wave (quarter, half) multiplies its quarter over two of the four patches, and the 400 staged
 // (pixel, block) units of an item are one per thread instead of four: per item a wave issues 72 MFMAs instead of 144 and
 // stages a quarter of what it did, with two waves per SIMD to overlap the phases.  Same chains, same combine: same bits.
+__device__ __forceinline__ void finalize_one(const FinalizeParams& p, int n, int c, unsigned long long I1, unsigned long long I2);
 template <int TH, int EPI, bool BF, int PS>
 __global__ __launch_bounds__(256 * PS) void conv3x3_ksplit(ConvParams p) {
     constexpr int NTHR = 256 * PS, MT = (TH / 4) * (TH / 4), PW = TH / 4;
@@ -931,6 +932,13 @@ __global__ __launch_bounds__(256 * PS) void conv3x3_ksplit(ConvParams p) {
     float* sB = sA + 2 * 4 * IMG;                     // [2][4][SEG]
     f32x4* sAff = reinterpret_cast<f32x4*>(sB + 2 * 4 * SEG);     // [2][4][16]
     f32x4* sP = sAff + 2 * 4 * 16;                    // [4 quarters][MT][64 lanes] partial accumulators
+    // fused finalize (p.fin_aff): the plane's sums over the MT finishing waves + their arrival count, behind sP (dynamic LDS too: a
+    // static __shared__ object would make the 160 KB dynamic-size attribute of prepare_kernel invalid)
+    unsigned long long (*sfin)[16] = reinterpret_cast<unsigned long long (*)[16]>(sP + 4 * MT * 64);
+    unsigned& sfin_cnt = *reinterpret_cast<unsigned*>(sfin + 2);
+    if (EPI == EPI_SYNTH && p.fin_aff != nullptr && threadIdx.x < 33) {
+        if (threadIdx.x < 32) sfin[threadIdx.x >> 4][threadIdx.x & 15] = 0ull; else sfin_cnt = 0u;      // visible after the first barrier of the item loop
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1070,7 +1078,22 @@ __global__ __launch_bounds__(256 * PS) void conv3x3_ksplit(ConvParams p) {
         unsigned long long I1 = to_fixed(sq, kStatScale1), I2 = to_fixed_sq(qq, stat_s2(p.H * p.W));
         I1 += shfl_xor_u64(I1, 16); I2 += shfl_xor_u64(I2, 16);
         I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
-        if (lane < 16) {
+        if (p.fin_aff != nullptr) {
+            // the tile is the whole plane: the MT finishing waves add their integer sums in LDS, the last one writes the coefficients
+            // (finalize_one, the tail of finalize_kernel: same bits) -- no partial rows, no finalize launch (round 4)
+            if (lane < 16) { atomicAdd(&sfin[0][i16], I1); atomicAdd(&sfin[1][i16], I2); }
+            __threadfence_block();
+            unsigned arrived = 0;
+            if (lane == 0) arrived = atomicAdd(&sfin_cnt, 1u);
+            arrived = __shfl(arrived, 0);
+            if (arrived == (unsigned)MT - 1u && lane < 16) {
+                __threadfence_block();
+                FinalizeParams f{};
+                f.HW = p.H * p.W; f.C = p.Cout; f.style = p.fin_style; f.style_stride = p.fin_style_stride;
+                f.gamma = p.fin_gamma; f.beta = p.fin_beta; f.aff = p.fin_aff; f.flags = p.fin_flags;
+                finalize_one(f, n, co, atomicAdd(&sfin[0][i16], 0ull), atomicAdd(&sfin[1][i16], 0ull));
+            }
+        } else if (lane < 16) {
             StatPart sp; sp.s1 = I1; sp.s2 = I2;
             p.partials[((size_t)n * p.prow + blockIdx.x * MT + mt) * p.Cout + co] = sp;
         }
@@ -4018,7 +4041,7 @@ template <int TH, int EPI, bool BF, int PS>
 static hipError_t launch_ksplit_t(const ConvParams& p, int n, hipStream_t s) {
     constexpr int MT = (TH / 4) * (TH / 4), PX = BF ? 8 : 16, TS = BF ? 128 : 256;
     constexpr int RS = (TH + 2) * PX + (BF ? 4 : 8), IMG = (TH + 2) * RS, SEG = 9 * TS;
-    const size_t lds = sizeof(float) * (2 * 4 * IMG + 2 * 4 * SEG) + sizeof(float4) * (2 * 4 * 16 + 4 * MT * 64);
+    const size_t lds = sizeof(float) * (2 * 4 * IMG + 2 * 4 * SEG) + sizeof(float4) * (2 * 4 * 16 + 4 * MT * 64) + 2 * 16 * sizeof(unsigned long long) + 16;
     auto kern = conv3x3_ksplit<TH, EPI, BF, PS>;
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
@@ -4566,6 +4589,11 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// whole-plane K-split tiles (4 and 8 px) finalize in the kernel when the caller supplies the finalize operands (GSA_FUSEFIN=0: never)
+bool conv_fuses_finalize(const ConvParams& p, int epi, bool sc) {
+    static const bool enabled = !(getenv("GSA_FUSEFIN") && atoi(getenv("GSA_FUSEFIN")) == 0);
+    return enabled && epi == EPI_SYNTH && conv_uses_ksplit(p, sc) && p.H == p.W && p.H <= 8 && !conv_uses_wino(p, epi, sc);
+}
 // post_fin_kernel: planes of at most 32 x 32 pixels with a multiple of 16 channels (GSA_FUSEFIN=0: the two separate launches)
 bool post_fuses_finalize(const PostParams& p) {
     static const bool enabled = !(getenv("GSA_FUSEFIN") && atoi(getenv("GSA_FUSEFIN")) == 0);
