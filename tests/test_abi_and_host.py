@@ -214,6 +214,30 @@ def test_dataset_writer_drain_surfaces_a_batch_level_error(tmp_path):
         w.close()
 
 
+def test_dataset_writer_withholds_the_files_of_a_batch_whose_device_check_failed(tmp_path):
+    """The in-flight device checks (include/gsa.h gsa_status_snapshot, reference main.py:93-104) on the host side, without a GPU:
+    the dispatcher looks at a batch's status words before it writes the batch's files; a non-zero word withholds that batch AND
+    every later one, and the error names the first withheld global index."""
+    import torch
+    from gan_segmentation_amd.dataset_writer import DatasetWriter, DeviceCheckFailed
+    g = np.random.default_rng(0)
+    img = g.integers(0, 256, (2, 32, 32, 3), dtype=np.uint8)
+    mask = g.integers(0, 2, (2, 32, 32), dtype=np.uint8)
+    w = DatasetWriter(str(tmp_path), workers=2)
+    w.submit(img, mask, 0, status=[torch.zeros(2, dtype=torch.int32)])
+    w.submit(img, mask, 2, status=[torch.zeros(2, dtype=torch.int32), torch.zeros(2, dtype=torch.int32)])      # two replicas, both clean
+    assert w.drain() == 4
+    w.submit(img, mask, 4, status=[torch.tensor([0, 0], dtype=torch.int32), torch.tensor([1, 0], dtype=torch.int32)])   # one replica's statistics word set
+    w.submit(img, mask, 6, status=[torch.zeros(2, dtype=torch.int32)])                                         # later batch: halted too
+    with pytest.raises(DeviceCheckFailed) as e:
+        w.close()
+    assert e.value.first_index == 4 and "global sample index 4" in str(e.value) and "instance-norm statistic" in str(e.value)
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted(["img_%06d.jpg" % i for i in range(4)] + ["mask_%06d.png" % i for i in range(4)])
+    # the mapping time-out word is named as such
+    assert "mapping network timed out" in str(DeviceCheckFailed(8, (0, 1)))
+
+
 def test_mask_png_bytes_decodes_back():
     """The writer's own PNG container (zlib level 1, run-length strategy): lossless, 8-bit greyscale, valid CRCs."""
     import io
