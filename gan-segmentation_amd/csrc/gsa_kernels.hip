@@ -39,6 +39,9 @@
 #endif
 // double-buffered (prefetch two items ahead, one barrier per item) form also for the 8x8 / 4x4 tiles of the 4^2-16^2 layers:
 // their 32 channel blocks were 32 dependent load -> LDS -> barrier rounds with ONE block in flight per workgroup
+#ifndef GSA_POST_OCC
+#define GSA_POST_OCC 2      // waves per SIMD the blur pass is compiled for (3 = 168 registers: 260-370 bytes of scratch, g.512.post_1 0.130 -> 0.343 ms)
+#endif
 #ifndef GSA_WINO_SOA
 #define GSA_WINO_SOA 0
 #endif
@@ -3067,7 +3070,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostParams p) {
 // r+2 are in flight while row r is computed, and the statistics of the RPT rows stay in registers until the end.
 // Same arithmetic in the same order per output (9-tap fmaf chain ky, kx ascending; zero padding = zeroed values).
 template <int RPT, bool BF>
-__global__ __launch_bounds__(256) void post_rows_kernel(PostParams p) {
+__global__ __launch_bounds__(256, GSA_POST_OCC) void post_rows_kernel(PostParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sstat[];   // [2][C]
     const int n = blockIdx.y;
     const int C4 = p.C >> 2, W4 = p.W >> 2;
