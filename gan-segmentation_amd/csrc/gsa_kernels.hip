@@ -1195,9 +1195,13 @@ __device__ __forceinline__ void mfma_settle(f32x4 (&a)[16]) {
 // activation image by the weights of two neighbouring 16-channel groups -- a layer with several groups stages (loads, AdaIN, LDS
 // writes) every input tile once per group, so sharing the image between two groups halves that work per MFMA; occupancy is
 // unchanged (one 8-wave workgroup per CU instead of two 4-wave ones).  Same arithmetic per output: same bits.
-template <int EPI, int NT, bool CHUNK, bool AFF, int GW = 1>      // AFF: the source carries AdaIN coefficients (p.aff0 != null) -- compile time, so that the
-__global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvParams p) {      // instantiations without it carry none of its code
-    constexpr int NTHR = 256 * GW, LH = 18, LW = 18, RS = LW * 16 + 4;
+// TW = 2 (round 4, VERDICT r3 item 5 in the only form that keeps the occupancy): ONE 512-thread workgroup on a 16x32 tile -- waves 0-3 the left
+// 16x16 half, waves 4-7 the right one, ONE staged 18x34 halo image (612 instead of 2 x 324 pixels), one barrier per item for both halves;
+// resident-weight layers only (both halves multiply by the same LDS panel), GW = 1.  Same arithmetic per output: same bits.
+template <int EPI, int NT, bool CHUNK, bool AFF, int GW = 1, int TW = 1>      // AFF: the source carries AdaIN coefficients (p.aff0 != null) -- compile time, so that the
+__global__ __launch_bounds__(256 * GW * TW, NT == 1 ? 2 / TW : 1) void conv3x3_wino(ConvParams p) {      // instantiations without it carry none of its code
+    static_assert(TW == 1 || (TW == 2 && GW == 1 && NT == 1), "two tiles per workgroup: one channel group, 16 output channels");
+    constexpr int NTHR = 256 * GW * TW, LH = 18, LW = 16 * TW + 2, RS = LW * 16 + 4;
     constexpr int SEG = 16 * 256;                // U floats per (16 couts, 16-channel block): 16 frequencies x [ci][16][cg]
     constexpr int NB4 = SEG / 4, BIT = NT * NB4 / 256;      // 16-byte pieces of one (16 couts, block) segment; pieces per thread of a block
     constexpr int NCH = CHUNK ? (LH * LW * 4 + NTHR - 1) / NTHR : (LH * LW + NTHR - 1) / NTHR;     // staging rounds per item (chunks or pixels)
@@ -1211,7 +1215,9 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave8 & 3, gsel = wave8 >> 2;      // quadrant of the tile; which of the workgroup's GW channel groups
+    const int wave = wave8 & 3;                         // quadrant of the (half) tile
+    const int gsel = TW == 2 ? 0 : wave8 >> 2;          // which of the workgroup's GW channel groups
+    const int tsel = TW == 2 ? wave8 >> 2 : 0;          // which 16x16 half of a 16x32 tile
     const int tid8 = tid & 255;                         // thread index inside its group's 256 threads (weight staging)
     const int i16 = lane & 15, kq = lane >> 4;
     // group_minor (launcher: one tile per workgroup, several channel groups, all weight panels together small enough for an
@@ -1235,11 +1241,11 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
     struct Tile { int n, y0, x0, row; };
     auto advance = [&](const Tile& t) {
         Tile u = t;
-        u.x0 += 16; u.row += 1;
+        u.x0 += 16 * TW; u.row += 1;
         if (u.x0 == p.W) { u.x0 = 0; u.y0 += 16; if (u.y0 == p.H) { u.y0 = 0; u.row = 0; u.n += 1; } }
         return u;
     };
-    auto is_edge = [&](const Tile& t) { return t.y0 == 0 || t.x0 == 0 || t.y0 + 16 == p.H || t.x0 + 16 == p.W; };
+    auto is_edge = [&](const Tile& t) { return t.y0 == 0 || t.x0 == 0 || t.y0 + 16 == p.H || t.x0 + 16 * TW == p.W; };
     const int part = tid & 3;                    // CHUNK: this thread's four channels of every 16-channel block
     int t_ly[NCH], t_lx[NCH], t_lds[NCH];        // tile-local coordinates / LDS offset of the units this thread stages
 #pragma unroll
@@ -1253,7 +1259,7 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
     for (int k = 0; k < NCH; ++k) t_rel[k] = t_lds[k] >= 0 ? t_ly[k] * p.W + t_lx[k] : 0;
     auto tile_chunks = [&](const Tile& t, Chunk (&tp)[NCH]) {
         const int base = (t.n * p.H + t.y0) * p.W + t.x0;
-        if (t.y0 == 0 || t.x0 == 0 || t.y0 + 16 == p.H || t.x0 + 16 == p.W) {      // wave-uniform: only edge tiles test their pixels
+        if (t.y0 == 0 || t.x0 == 0 || t.y0 + 16 == p.H || t.x0 + 16 * TW == p.W) {      // wave-uniform: only edge tiles test their pixels
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 const int gy = t.y0 + t_ly[k], gx = t.x0 + t_lx[k];
@@ -1268,7 +1274,7 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
     };
     // A operand: the 4x4 input patch of this lane's Winograd tile (halo coordinates), k slot kq
     const int wty = ((i16 >> 3) & 1) * 2 + ((i16 >> 1) & 1), wtx = ((i16 >> 2) & 1) * 2 + (i16 & 1);
-    const int pbase = ((wave >> 1) * 8 + 2 * wty) * RS + ((wave & 1) * 8 + 2 * wtx) * 16 + kq * 4;
+    const int pbase = ((wave >> 1) * 8 + 2 * wty) * RS + (tsel * 16 + (wave & 1) * 8 + 2 * wtx) * 16 + kq * 4;
     const int bbase = (kq * 16 + i16) * 4;
 
     f32x4 acc[16][NT];
@@ -1367,7 +1373,7 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
     // ---- epilogue geometry: lane -> (channel = lane & 15, 4x4 output patch (b3, b2) = lane >> 4 of the wave's quadrant);
     // registers after the output transform: row r of the patch as an x-quad
     const int xj = lane & 3, cq4 = ((lane >> 2) & 3) * 4;     // quad-transposed store layout
-    const int prow0 = (wave >> 1) * 8 + ((lane >> 5) & 1) * 4, pcol0 = (wave & 1) * 8 + ((lane >> 4) & 1) * 4;
+    const int prow0 = (wave >> 1) * 8 + ((lane >> 5) & 1) * 4, pcol0 = tsel * 16 + (wave & 1) * 8 + ((lane >> 4) & 1) * 4;
     const int co0 = g * (16 * NT);                        // first output channel of the group
     const unsigned lane_out = (unsigned)((prow0 * p.W + pcol0 + xj) * p.Cout + co0 + cq4);
     const unsigned lane_nz = (unsigned)(prow0 * p.W + pcol0);
@@ -1483,7 +1489,7 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
                 I1 += shfl_xor_u64(I1, 32); I2 += shfl_xor_u64(I2, 32);
                 if (lane < 16) {
                     StatPart sp; sp.s1 = I1; sp.s2 = I2;
-                    p.partials[((size_t)tc.n * p.prow + tc.row * 4 + wave) * p.Cout + co0 + nt * 16 + i16] = sp;
+                    p.partials[((size_t)tc.n * p.prow + tc.row * (4 * TW) + (TW == 2 ? wave8 : wave)) * p.Cout + co0 + nt * 16 + i16] = sp;
                 }
             }
         }
@@ -1541,7 +1547,7 @@ __global__ __launch_bounds__(256 * GW, NT == 1 ? 2 : 1) void conv3x3_wino(ConvPa
     Tile tc, tr;
     {
         const int tx = w_begin % p.tiles_x, r = w_begin / p.tiles_x;
-        tc.x0 = tx * 16; tc.y0 = (r % p.tiles_y) * 16; tc.n = r / p.tiles_y; tc.row = (r % p.tiles_y) * p.tiles_x + tx;
+        tc.x0 = tx * 16 * TW; tc.y0 = (r % p.tiles_y) * 16; tc.n = r / p.tiles_y; tc.row = (r % p.tiles_y) * p.tiles_x + tx;
     }
     int cb = 0, cbr = 0;
     Chunk tpr[NCH];
@@ -4099,13 +4105,14 @@ static int wino_nt(const ConvParams& p) {
     return (forced >= 2 && p.Cout % 32 == 0) ? 2 : 1;
 }
 
-template <int EPI, int NT, bool CHUNK, bool AFF, int GW>
+template <int EPI, int NT, bool CHUNK, bool AFF, int GW, int TW = 1>
 static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
-    constexpr int RS = 18 * 16 + 4, SEG = 16 * 256;
+    constexpr int RS = (16 * TW + 2) * 16 + 4, SEG = 16 * 256;
     const int nblk = p.C0 / 16;
     const bool wres = (size_t)nblk * NT * SEG * sizeof(float) <= (NT == 1 ? 36 : 72) * 1024;      // whole panel of the group resident (<= 32 input channels)
     const size_t lds = sizeof(float) * (2 * 18 * RS + (wres ? nblk : 2) * GW * NT * SEG) + (CHUNK ? 0 : 32 * sizeof(float4));
-    auto kern = conv3x3_wino<EPI, NT, CHUNK, AFF, GW>;
+    auto kern = conv3x3_wino<EPI, NT, CHUNK, AFF, GW, TW>;
+    if (TW == 2 && !wres) return hipErrorInvalidValue;      // two tiles per workgroup: resident weight panel only
     if (p.device < 0 || p.device >= kMaxDevices) return hipErrorInvalidDevice;
     static LaunchState states[kMaxDevices];
     int num_cus = 0, wgs_per_cu = 0;
@@ -4119,7 +4126,7 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
             if (st.occ_lds[i] == lds) wgs_per_cu = st.occ_k[i];
         if (!wgs_per_cu) {
             int k = 0;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, reinterpret_cast<const void*>(kern), 256 * GW, lds);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, reinterpret_cast<const void*>(kern), 256 * GW * TW, lds);
             if (e != hipSuccess) return e;
             wgs_per_cu = k < 1 ? 1 : (k > 8 ? 8 : k);
             if (st.occ_n < 8) { st.occ_lds[st.occ_n] = lds; st.occ_k[st.occ_n] = wgs_per_cu; ++st.occ_n; }
@@ -4129,10 +4136,10 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     ConvParams q = p;
     q.wpk = p.wino;
     q.w_resident = wres ? 1 : 0;
-    q.tiles_x = p.W / 16;
+    q.tiles_x = p.W / (16 * TW);
     q.tiles_y = p.H / 16;
     q.groups = p.Cout / (16 * NT * GW);      // workgroup-level groups: GW channel groups of 16*NT each per workgroup
-    q.prow = q.tiles_x * q.tiles_y * 4;
+    q.prow = q.tiles_x * q.tiles_y * 4 * TW;
     q.total_tiles = q.tiles_x * q.tiles_y * n;         // per output-channel group
     // persistent workgroups; a workgroup stays inside its channel group
     const int slots = std::max(1, num_cus * wgs_per_cu / q.groups);
@@ -4154,8 +4161,8 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
     static const bool gm_enabled = !(getenv("GSA_WINO_GM") && atoi(getenv("GSA_WINO_GM")) == 0);
     q.group_minor = (gm_enabled && !persistent && q.groups > 1 && q.total_tiles % 8 == 0 &&
                      (size_t)16 * p.C0 * p.Cout * sizeof(float) <= (size_t)2 << 20) ? 1 : 0;
-    if (q.group_minor) hipLaunchKernelGGL(kern, dim3(q.total_tiles * q.groups), dim3(256 * GW), lds, s, q);
-    else hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256 * GW), lds, s, q);
+    if (q.group_minor) hipLaunchKernelGGL(kern, dim3(q.total_tiles * q.groups), dim3(256 * GW * TW), lds, s, q);
+    else hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256 * GW * TW), lds, s, q);
     return hipGetLastError();
 }
 
@@ -4270,8 +4277,19 @@ static hipError_t launch_wino_dma(const ConvParams& p, int epi, int n, hipStream
     return p.aff0 ? launch_wino_dma_t<EPI_DEC, true>(p, n, s) : launch_wino_dma_t<EPI_DEC, false>(p, n, s);
 }
 
+// two 16x16 tiles per 8-wave workgroup (conv3x3_wino<..., TW = 2>): the layers with ONE output-channel group and a resident panel
+// (16 output channels from <= 32 inputs: g.1024.conv_2, d.cvt_8, d.main_7.b), whole-pixel staging.  GSA_WINO_TW=2 selects it (speed only).
+static int wino_tw(const ConvParams& p) {
+    static const int forced = getenv("GSA_WINO_TW") ? atoi(getenv("GSA_WINO_TW")) : 1;
+    return (forced == 2 && p.Cout == 16 && p.C0 <= 32 && p.W % 32 == 0 && wino_nt(p) == 1 && !wino_chunk(p)) ? 2 : 1;
+}
+
 static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s) {
     if (wino_dma(p, epi) && wino_nt(p) == 1) return launch_wino_dma(p, epi, n, s);
+    if (wino_tw(p) == 2) {
+        if (epi == EPI_SYNTH) return p.aff0 ? launch_wino_t<EPI_SYNTH, 1, false, true, 1, 2>(p, n, s) : launch_wino_t<EPI_SYNTH, 1, false, false, 1, 2>(p, n, s);
+        return p.aff0 ? launch_wino_t<EPI_DEC, 1, false, true, 1, 2>(p, n, s) : launch_wino_t<EPI_DEC, 1, false, false, 1, 2>(p, n, s);
+    }
     const int nt = wino_nt(p);
     const int gw = wino_gw(p);
     const bool ch = wino_chunk(p);
@@ -4297,6 +4315,10 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     }
     if (conv_uses_wino(p, epi, sc) && wino_dma(p, epi) && wino_nt(p) == 1) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_wino_dma<%d, %s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false");
+        return buf;
+    }
+    if (conv_uses_wino(p, epi, sc) && wino_tw(p) == 2) {
+        snprintf(buf, sizeof buf, "void gsa::conv3x3_wino<%d, 1, false, %s, 1, 2>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false");
         return buf;
     }
     if (conv_uses_wino(p, epi, sc)) {

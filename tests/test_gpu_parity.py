@@ -845,7 +845,7 @@ print("SWITCH_OK")
 @pytest.mark.parametrize("env", [{"GSA_WINO_NT": "2"}, {"GSA_WINO_GM": "0"}, {"GSA_WINO_CHUNK": "1"}, {"GSA_WINO_CHUNK": "0"}, {"GSA_POST_RPT": "1"}, {"GSA_POST_RPT": "8"},
                                  {"GSA_SIDE_LEVELS": "0"}, {"GSA_MAPFUSE": "0"}, {"GSA_KSPLIT_PS": "1"}, {"GSA_FEWROWS": "0"}, {"GSA_WRES": "0", "GSA_SUBRES": "0", "GSA_STATS_DIRECT": "0"},
                                  {"GSA_WINO_GW": "1"}, {"GSA_WINO_GW": "2"}, {"GSA_WINO_PERS": "32"}, {"GSA_POST_NG": "4"}, {"GSA_SUBWST": "0"},      # round 3
-                                 {"GSA_WINO_DMA": "1"}, {"GSA_FUSEFIN": "0"}])      # round 4: conv3x3_wino_dma (every operand by LDS-DMA); post pass and finalize as two launches
+                                 {"GSA_WINO_DMA": "1"}, {"GSA_FUSEFIN": "0"}, {"GSA_WINO_TW": "2"}])      # round 4: conv3x3_wino_dma (every operand by LDS-DMA); post pass and finalize as two launches; two tiles per 8-wave workgroup
 def test_speed_switches_do_not_change_the_bits(torch_cuda, tmp_path, env):
     """The A/B switches of DESIGN.md section 4 that are NOT part of the canonical arithmetic (channel tile of the Winograd
     kernel, group order, rows per thread of the post kernel, stream overlap, resident weights / persistent forms / direct
