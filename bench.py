@@ -213,6 +213,39 @@ def measure_end_to_end(gen, B, steps, dev):
     return out
 
 
+def measure_generate_job(gan, n, batch, dev):
+    """BASELINE.json configs[2]'s workload on ONE card, as the reference runs it (main.py:75-104): `main.py generate` end to end --
+    .params files loaded from disk, `n` samples in batches of `batch` (the 8-GPU node's global batch of 32 on a single GPU),
+    counter-based inputs, GPU JPEG/PNG encoders, the in-flight status checks, img_%06d.jpg + mask_%06d.png on disk.  Timed: the
+    whole call, model load included, after a one-batch call that only warms the process (library load, first allocation)."""
+    import shutil
+    import tempfile
+    from gan_segmentation_amd import main as cli
+    from gan_segmentation_amd import params as P
+    from gan_segmentation_amd import weights as W
+    mr = W.GAN_MAX_RES_LOG2[gan]
+    d = tempfile.mkdtemp(prefix="gsa_job_")
+    try:
+        os.makedirs(os.path.join(d, "models"))
+        os.makedirs(os.path.join(d, "exp", "checkpoints"))
+        P.save_params(os.path.join(d, "models", "stylegan-%s.params" % gan), W.synthetic_generator_params(W.generator_config(mr)))
+        P.save_params(os.path.join(d, "exp", "checkpoints", "checkpoint_last.params"), W.synthetic_decoder_params(W.decoder_config(mr)))
+        cfg = {"BASE_DIR": os.path.join(d, "exp"), "GAN": gan, "GAN_DIR": os.path.join(d, "models"), "GAN_GPU_IDS": [dev.index],
+               "GAN_BATCH_SIZE_PER_GPU": batch, "SOLVER_GPU_IDS": [dev.index], "ANNOTATION": "segmentation", "GENERATE_NUM": n}
+        rc = cli.generate(cfg, limit=batch)
+        t0 = time.perf_counter()
+        rc = rc or cli.generate(cfg, limit=n)
+        dt = time.perf_counter() - t0
+        dst = os.path.join(d, "exp", "dataset", "train_generated")
+        names = os.listdir(dst)
+        return {"generate_job": "main.py generate: %s, %d samples, batch %d, 1 GPU (BASELINE.json configs[2]'s workload on one card), "
+                                "synthetic .params loaded from disk, files written to a temporary directory" % (gan, n, batch),
+                "generate_job_rc": rc, "generate_job_s": round(dt, 3), "generate_job_pairs_per_s": round(n / dt, 2),
+                "generate_job_files": len(names), "generate_job_bytes": sum(os.path.getsize(os.path.join(dst, f)) for f in names)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 class TimedLoop:
     """The N-rank control flow of the timed region, free of any GPU call so that a world-size-2 gloo test can drive it
     with a stub producer (tests/test_abi_and_host.py): per step wait for the slot's previous gather, produce into the
@@ -275,19 +308,30 @@ class TimedLoop:
             seconds = float(t.item())
         return seconds
 
-    def run(self, warmup, steps):
+    def run(self, warmup, steps, repeats=1):
+        """Warm-up, then `repeats` timed regions back to back, each EXACTLY `steps` steps between two fences (barrier + device
+        sync on both sides).  `dts_local` holds every region's seconds, `dt_local` their median."""
         t1 = time.perf_counter()
         for _ in range(warmup):
             self.step()
         self.fence()
         self.agree_on_fallback()
         t_warm = time.perf_counter() - t1
-        t0 = time.perf_counter()
-        for _ in range(steps):               # EXACTLY `steps` steps between two fences
-            self.step()
-        self.fence()
-        dt = time.perf_counter() - t0
-        return {"warmup_s": t_warm, "dt_local": dt, "gather": self.gather, "last_slot": (self.k - 1) % self.gat.depth}
+        dts = []
+        for _ in range(max(1, repeats)):
+            t0 = time.perf_counter()
+            for _ in range(steps):               # EXACTLY `steps` steps between two fences
+                self.step()
+            self.fence()
+            dts.append(time.perf_counter() - t0)
+        return {"warmup_s": t_warm, "dt_local": median(dts), "dts_local": dts, "gather": self.gather,
+                "last_slot": (self.k - 1) % self.gat.depth}
+
+
+def median(xs):
+    """Middle element of the sorted values (the upper one of an even count): always one of the measured regions."""
+    ys = sorted(xs)
+    return ys[len(ys) // 2]
 
 
 def self_launch(n, argv):
@@ -367,24 +411,27 @@ def roofline_of(top, precision, traffic):
     separately as `algorithmic_tflops` / `algorithmic_frac`, which CAN exceed 1 and is not a utilisation."""
     sec = top["ms"] * 1e-3
     launches = max(1, top["launches"])
+    mfma_peak = PEAK_FP32_TFLOPS if precision == "fp32" else PEAK_BF16_TFLOPS      # the MFMA peak of the precision the kernel multiplies in
     ex_tf = top["flops"] / sec / 1e12 if sec > 0 else 0.0
     alg_tf = top["alg_flops"] / sec / 1e12 if sec > 0 else 0.0
     gbs = top["bytes"] / sec / 1e9 if sec > 0 else 0.0
-    t_mfma = top["flops"] / (PEAK_FP32_TFLOPS * 1e12)
+    t_mfma = top["flops"] / (mfma_peak * 1e12)
     t_hbm = top["bytes"] / (PEAK_HBM_GBS * 1e9)
-    hbm_bound = precision == "bf16" or t_hbm > t_mfma     # bf16 mode: 16x the MFMA rate, the same kernels sit under the HBM roof
+    hbm_bound = t_hbm > t_mfma     # bf16 mode: 16x the MFMA rate, the same kernels sit under the HBM roof
     if hbm_bound:
         bound, ach, peak, unit = "hbm", gbs, PEAK_HBM_GBS, "GB/s"
     else:
-        bound, ach, peak, unit = "mfma", ex_tf, PEAK_FP32_TFLOPS, "TFLOP/s"
+        bound, ach, peak, unit = "mfma", ex_tf, mfma_peak, "TFLOP/s"
     return {"bound": bound, "kernel": top["name"], "achieved": round(ach, 3), "peak": peak, "unit": unit,
             "frac": round(ach / peak, 4),
-            "executed_tflops": round(ex_tf, 3), "executed_frac_of_mfma_peak": round(ex_tf / PEAK_FP32_TFLOPS, 4),
+            "mfma_peak_tflops": mfma_peak,
+            "executed_tflops": round(ex_tf, 3), "executed_frac_of_mfma_peak": round(ex_tf / mfma_peak, 4),
             "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
-            "algorithmic_tflops": round(alg_tf, 3), "algorithmic_frac": round(alg_tf / PEAK_FP32_TFLOPS, 4),
+            "algorithmic_tflops": round(alg_tf, 3), "algorithmic_frac": round(alg_tf / mfma_peak, 4),
             "avg_launch_ms": round(top["ms"] / launches, 4), "launches": top["launches"],
-            "note": "achieved/frac = EXECUTED FLOP of the kernel (Winograd F(4x4,3x3): 36 products per 16 outputs, F(2x2,3x3): 16 per 4; "
-                    "sub-pixel form: 4 taps instead of 9) / time / the f32 MFMA peak -- the utilisation of the matrix pipe; "
+            "note": "achieved/frac = EXECUTED FLOP of the kernel (Winograd F(2x2,3x3): 16 products per 4 outputs, F(2x2,2x2): 9 per 4; "
+                    "sub-pixel form: 4 taps instead of 9) / time / the MFMA peak of the precision (157.3 TF f32, 2500 TF dense bf16) -- the "
+                    "utilisation of the matrix pipe; "
                     "algorithmic_* = the same layers in the reference's direct formulation (SURVEY.md 8d), a throughput that can exceed the peak",
             "measured": "HIP events around every launch in a second pass of the same K steps, run right after the timed region with "
                         "the decoder-beside-synthesis stream overlap off (durations not stretched by a concurrent kernel)",
@@ -409,11 +456,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50, help="timed steps (default 50: a third of a second of GPU time at FFHQ batch 8)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps each, back to back after ONE warm-up; value = their median, every region is printed (runs)")
     ap.add_argument("--gan", default="ffhq", choices=("ffhq", "cars", "bedrooms"))
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU per step")
     ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"),
                     help="bf16 = bf16 MFMA operands, fp32 accumulate/statistics (BASELINE.json configs[4]); "
                          "the headline metric is fp32")
+    ap.add_argument("--job-samples", type=int, default=2000,
+                    help="samples of the `main.py generate` job timed under end_to_end (batch 32, files on disk; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of configs[3]/[4] and the end-to-end rate")
     ap.add_argument("--allow-blocking", action="store_true",
@@ -466,15 +517,15 @@ def main():
         gat = gdist.PairGatherer(B, R, nch, device=dev, dst=0, depth=2)
         producer = StubProducer(rank, B, R, nch)
         loop = TimedLoop(producer, gat, world, dev, args.allow_blocking)
-        timing = loop.run(args.warmup, args.steps)
-        dt = loop.max_over_ranks(timing["dt_local"])
+        timing = loop.run(args.warmup, args.steps, args.repeats)
+        dt = median([loop.max_over_ranks(d) for d in timing["dts_local"]])
         if rank == 0:
             # content and order of the last gathered batch: rank r's row must hold rank r's pairs of the last step
             ok = True
             if timing["gather"] != "blocking":
                 parts = gat.result(timing["last_slot"])
                 for r in range(ranks):
-                    wi, wm = StubProducer(r, B, R, nch).pairs(args.warmup + args.steps - 1)
+                    wi, wm = StubProducer(r, B, R, nch).pairs(args.warmup + args.steps * max(1, args.repeats) - 1)
                     ok = ok and bool(torch.equal(parts[r][0], wi)) and bool(torch.equal(parts[r][1], wm))
             print(json.dumps({
                 "metric": "bench.py control-flow rehearsal (stub producer, NOT a measurement)",
@@ -516,8 +567,8 @@ def main():
     t_setup = time.perf_counter() - t_proc
     # ---- timed region: EXACTLY K steps (no per-launch events here: 2 event packets around each of the
     # ~130 launches of a step cost ~5 % of the step)
-    timing = loop.run(args.warmup, args.steps)
-    t_warm, dt, state, last_slot = timing["warmup_s"], timing["dt_local"], {"gather": timing["gather"]}, timing["last_slot"]
+    timing = loop.run(args.warmup, args.steps, args.repeats)
+    t_warm, state, last_slot = timing["warmup_s"], {"gather": timing["gather"]}, timing["last_slot"]
     # ---- roofline pass (untimed): the same K steps with every launch bracketed by HIP events on its
     # stream, and with the decoder/synthesis stream overlap off, so that a kernel's duration is its own
     # and not stretched by the kernel running beside it
@@ -532,7 +583,8 @@ def main():
     ctx.profile_enable(0)
     ctx.set_overlap(-1)        # back to the default (by batch size)
     t_prof = time.perf_counter() - t1
-    dt = loop.max_over_ranks(dt)
+    dts = [loop.max_over_ranks(d) for d in timing["dts_local"]]      # per region: the slowest rank
+    dt = median(dts)
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -554,6 +606,10 @@ def main():
             "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "ranks": ranks, "devices": devices, "launcher": launcher,
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
+            # the spread of the headline: `repeats` regions of exactly `steps` steps each, back to back after one warm-up; value and
+            # ms_per_step are the MEDIAN region's, runs[] holds every region in the order it was timed
+            "repeats": len(dts), "runs": [round(world * B * args.steps / d, 3) for d in dts],
+            "min": round(world * B * args.steps / max(dts), 3), "max": round(world * B * args.steps / min(dts), 3),
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "stylegan-%s %d^2 synthesis + %d-class decoder, batch=%d per GPU, %s; "
                                    "synthetic weights/latents/noise; (img u8, mask u8) resident on rank 0"
@@ -601,10 +657,13 @@ def main():
                     e["name"], e["ms"] / args.steps, e["flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] else 0,
                     e["alg_flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] else 0,
                     e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["ms"] else 0), file=sys.stderr)
-        wall = {"setup": round(t_setup, 2), "warmup": round(t_warm, 3), "timed": round(dt, 4), "profile_pass": round(t_prof, 3)}
+        wall = {"setup": round(t_setup, 2), "warmup": round(t_warm, 3), "timed": round(sum(dts), 4), "timed_median_region": round(dt, 4),
+                "profile_pass": round(t_prof, 3)}
         if world == 1 and not args.no_secondary:
             t1 = time.perf_counter()
             out["end_to_end"] = measure_end_to_end(gen, B, max(4, min(args.steps, 20)), dev)
+            if args.gan == "ffhq" and args.precision == "fp32" and args.job_samples > 0:
+                out["end_to_end"].update(measure_generate_job("ffhq", args.job_samples, 32, dev))
             sec = []
             if (args.gan, args.precision, B) != ("bedrooms", "fp32", 64):
                 sec.append(measure_secondary("bedrooms", 64, "fp32", 10, 2, dev))      # BASELINE.json configs[3]

@@ -887,7 +887,12 @@ int gsa_check(gsa_ctx* c) {
 
 int gsa_status_snapshot(gsa_ctx* c, void* stream, uint32_t* host_words) {
     if (!c || !host_words) return fail(c, GSA_ERR_INVALID, "gsa_status_snapshot: null argument");
-    if (!c->map_ctl) return fail(c, GSA_ERR_STATE, "gsa_status_snapshot before the first generator step (no workspace yet)");
+    if (!c->map_ctl) {
+        // no workspace yet: no step of this context has run, so there is nothing to report -- a replica of an in-process device list
+        // that has not received a slice so far (ImageGenerator(gpu_ids=[a, b]) with one sample: split_sizes drops empty slices)
+        host_words[0] = host_words[1] = 0u;
+        return GSA_OK;
+    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(host_words, c->map_ctl, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     return GSA_OK;
@@ -895,6 +900,9 @@ int gsa_status_snapshot(gsa_ctx* c, void* stream, uint32_t* host_words) {
 
 int gsa_debug_inject(gsa_ctx* c, int32_t kind, int32_t arg) {
     if (!c) return GSA_ERR_INVALID;
+    // doubly gated: the explicit call AND GSA_TEST_HOOKS=1 in the environment of the process (the tests set it; neither alone arms anything)
+    const char* hooks = getenv("GSA_TEST_HOOKS");
+    if (!hooks || atoi(hooks) != 1) return fail(c, GSA_ERR_STATE, "gsa_debug_inject: test hooks are off (GSA_TEST_HOOKS=1 enables them)");
     switch (kind) {
     case 0: c->fault = 0; c->fault_range_after = -1; return GSA_OK;
     case 1: case 2: c->fault = kind; return GSA_OK;

@@ -87,6 +87,11 @@ bool conv_uses_ksplit(const ConvParams& p, bool shortcut);         // true: 4-wa
 bool conv_uses_wino43(const ConvParams& p, int epi, bool shortcut); // true: Winograd F(4x4,3x3) form (static rule: layer shape only; p.wino then holds the 36-frequency panel)
 bool wino43_enabled();                                              // GSA_WINO43 != 0
 bool conv_uses_wino(const ConvParams& p, int epi, bool shortcut);   // true: Winograd form (static rule: layer shape only)   // true: wave-specialised kernel, no partial rows
+// gsa_wino_lean.hip (round 5): the Winograd layers with one 16-channel input block and one 16-channel output group in a leaner
+// instruction stream -- speed only, the same arithmetic and bits as conv3x3_wino (GSA_WINO_LEAN=0 keeps conv3x3_wino)
+bool wino_lean_applies(const ConvParams& p, int epi);
+const char* wino_lean_name(const ConvParams& p, int epi);
+hipError_t launch_wino_lean(const ConvParams& p, int epi, int n, hipStream_t s);
 hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);   // deconv4x4s2 / sub-pixel up+conv
 bool subpixel_uses_wino(const ConvParams& p);                      // true: Winograd F(2x2,2x2) form (static rule: fp32 mode): 9 products per 2x2 class outputs instead of 163x3
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s);

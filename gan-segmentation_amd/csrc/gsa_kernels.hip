@@ -4285,6 +4285,10 @@ static int wino_tw(const ConvParams& p) {
 }
 
 static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s) {
+    if (wino_lean_applies(p, epi)) {
+        if (p.stat_rows_host) *p.stat_rows_host = 0;
+        return launch_wino_lean(p, epi, n, s);
+    }
     if (wino_dma(p, epi) && wino_nt(p) == 1) return launch_wino_dma(p, epi, n, s);
     if (wino_tw(p) == 2) {
         if (epi == EPI_SYNTH) return p.aff0 ? launch_wino_t<EPI_SYNTH, 1, false, true, 1, 2>(p, n, s) : launch_wino_t<EPI_SYNTH, 1, false, false, 1, 2>(p, n, s);
@@ -4313,6 +4317,7 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_wino43<%d>(gsa::ConvParams)", epi);
         return buf;
     }
+    if (conv_uses_wino(p, epi, sc) && wino_lean_applies(p, epi)) return wino_lean_name(p, epi);
     if (conv_uses_wino(p, epi, sc) && wino_dma(p, epi) && wino_nt(p) == 1) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_wino_dma<%d, %s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false");
         return buf;

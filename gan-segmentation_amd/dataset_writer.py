@@ -86,8 +86,16 @@ class DeviceCheckFailed(RuntimeError):
     """A batch's status snapshot (``ImageGenerator.snapshot_status``) was non-zero: ``first_index`` is the global index of
     the first sample whose files were withheld; every file below it was checked clean."""
 
-    def __init__(self, first_index, words):
+    def __init__(self, first_index, words, after=None):
         self.first_index, self.words = int(first_index), tuple(int(w) for w in words)
+        if after is not None:
+            # a LATER batch of a run that already failed: its own words were never looked at -- it is withheld because of the
+            # first failure, whose cause `after` carries (no cause is made up for this batch)
+            self.first_failure = after
+            super().__init__("batch starting at global sample index %d withheld: the run failed its device-side check at index %d (%s)"
+                             % (self.first_index, after.first_index, after))
+            return
+        self.first_failure = self
         what = []
         if self.words[0]:
             what.append("an instance-norm statistic left the range of its 64-bit fixed-point sum")
@@ -97,10 +105,16 @@ class DeviceCheckFailed(RuntimeError):
                          "index %d on were not written, everything below is valid" % (self.first_index, "; ".join(what), self.first_index))
 
 
+STATUS_RING_DEPTH = 32      # pinned status slots ImageGenerator.snapshot_status() cycles through: more batches than this may never be in flight
+
+
 class DatasetWriter:
     """``submit(img, mask, first_index)`` returns immediately; ``close()`` waits for every file."""
 
     def __init__(self, dst_dir, workers=None, slots=3, jpeg_quality=95, gpu_jpeg=False, jpeg_restart=None, gpu_png=False):
+        if not 1 <= slots < STATUS_RING_DEPTH:
+            raise ValueError("slots must be in [1, %d): a batch's status slot (ImageGenerator.snapshot_status) is reused after "
+                             "%d later batches" % (STATUS_RING_DEPTH, STATUS_RING_DEPTH))
         self.dst_dir = dst_dir
         os.makedirs(dst_dir, exist_ok=True)
         self.jpeg_quality = jpeg_quality
@@ -120,7 +134,7 @@ class DatasetWriter:
         self._lock = threading.Lock()
         self._copy_stream = None
         self._status = {}                    # first_index -> pinned status slots of that batch (or None)
-        self._halted = False                 # a batch failed its device-side check: nothing from there on is written
+        self._halted = None                  # the DeviceCheckFailed of the first batch that failed its device-side check: nothing from there on is written
         self._dispatcher = threading.Thread(target=self._dispatch, daemon=True)
         self._dispatcher.start()
         self.written = 0
@@ -135,7 +149,8 @@ class DatasetWriter:
         if self._errors:
             raise self._errors[0]
         self.submitted += int(img.shape[0])
-        self._status[first_index] = status
+        with self._lock:
+            self._status[first_index] = status
         if isinstance(img, np.ndarray):
             self._pending.put((None, None, np.ascontiguousarray(img), np.ascontiguousarray(mask), first_index))
             return
@@ -254,14 +269,18 @@ class DatasetWriter:
                     ev.synchronize()
                 # the copy stream waited for the producing stream, so the 8-byte status copy enqueued there before submit()
                 # has landed: look at it BEFORE any file of this batch exists
-                status = self._status.pop(first, None)
-                if self._halted:
-                    raise DeviceCheckFailed(first, (1, 0))
+                with self._lock:
+                    status = self._status.pop(first, None)
+                    halted = self._halted
+                if halted is not None:
+                    raise DeviceCheckFailed(first, halted.words, after=halted)
                 if status is not None:
                     words = [int(v) for t in status for v in t.tolist()]
                     if any(words):
-                        self._halted = True
-                        raise DeviceCheckFailed(first, (any(words[0::2]), any(words[1::2])))
+                        failure = DeviceCheckFailed(first, (any(words[0::2]), any(words[1::2])))
+                        with self._lock:
+                            self._halted = failure      # the first failing batch and ITS words: later batches refer to it
+                        raise failure
                 if isinstance(img, dict):         # (partly) compressed on the GPU
                     p = img
                     scans = self._fetch_encoded(slot, "jpeg", *p["jpeg"][1:]) if "jpeg" in p else None

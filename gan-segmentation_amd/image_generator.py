@@ -17,6 +17,7 @@ import torch
 
 from . import weights as _weights
 from ._runtime import current_stream_ptr, split_sizes, to_device_f32
+from .dataset_writer import STATUS_RING_DEPTH
 from .networks_seg import Decoder
 from .networks_stylegan import Generator
 
@@ -217,12 +218,12 @@ class ImageGenerator:
             # `_GRAPH_CAPTURES_MAX` times in its life (a caller whose addresses keep changing stays eager instead of re-capturing)
             if (seen[key] >= self.graph_after and model.ctx._checked_first_step
                     and model.__dict__.get("_graph_captures", 0) < _GRAPH_CAPTURES_MAX):
-                model.__dict__["_graph_captures"] = model.__dict__.get("_graph_captures", 0) + 1
                 if len(cache) >= 8:
                     cache.pop(next(iter(cache)))
                 if len(seen) > 64:
                     seen.clear()
                 graph = self._capture(model, dev, n, z, nptrs, img, mask)
+                model.__dict__["_graph_captures"] = model.__dict__.get("_graph_captures", 0) + 1      # only a capture that succeeded counts
                 graph.replay()
                 cache[key] = graph
                 return img, mask
@@ -244,8 +245,16 @@ class ImageGenerator:
             graph.capture_begin(capture_error_mode="thread_local")
             try:
                 model.ctx.generate(side.cuda_stream, n, z.data_ptr(), nptrs, img.data_ptr(), mask.data_ptr())
-            finally:
-                graph.capture_end()
+            except BaseException:
+                # the step failed while it was being recorded: end the (now invalid) capture, but let the ORIGINAL error through --
+                # capture_end raises on an invalidated capture and would hide it
+                try:
+                    graph.capture_end()
+                except Exception:
+                    pass
+                cur.wait_stream(side)
+                raise
+            graph.capture_end()
         cur.wait_stream(side)
         return graph
 
@@ -281,10 +290,10 @@ class ImageGenerator:
         call has completed; non-zero = that batch (or an earlier one since the last clean look) must be discarded."""
         ring = self.__dict__.get("_status_ring")
         if ring is None:
-            ring = self.__dict__["_status_ring"] = [torch.zeros((32, 2), dtype=torch.int32).pin_memory() for _ in self._gens]
+            ring = self.__dict__["_status_ring"] = [torch.zeros((STATUS_RING_DEPTH, 2), dtype=torch.int32).pin_memory() for _ in self._gens]
             self.__dict__["_status_next"] = 0
         k = self.__dict__["_status_next"]
-        self.__dict__["_status_next"] = (k + 1) % 32
+        self.__dict__["_status_next"] = (k + 1) % STATUS_RING_DEPTH
         views = []
         dev0 = self._gens[0]._model.device
         for g, slots in zip(self._gens, ring):

@@ -200,7 +200,9 @@ int gsa_check(gsa_ctx* ctx);
  * releases that batch's files).  Does not clear the words: gsa_check does. */
 int gsa_status_snapshot(gsa_ctx* ctx, void* stream, uint32_t* host_words);
 
-/* Test hook -- armed by this call only, never by the environment (the product never calls it):
+/* Test hook (the product never calls it) -- doubly gated: it arms something only when THIS call is made AND the process runs with
+ * GSA_TEST_HOOKS=1 (tests/conftest.py sets it); without the variable the call returns GSA_ERR_STATE, and the variable alone arms
+ * nothing:
  *   kind 0  disarm everything;
  *   kind 1  the fused mapping network is launched one workgroup short (its exchange times out: GSA_ERR_DEVICE at the check);
  *   kind 2  the NEXT generator pass returns GSA_ERR_HIP between a statistics producer and its finalize (dirty rows);

@@ -546,6 +546,34 @@ def test_bench_roofline_fields_are_fractions():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0.45 < r["frac"] < 0.55 and r["traffic"] == 1.2e9
     t_mfma, t_hbm = bench.roof_seconds([wino, blur], "fp32")
     assert abs(t_mfma - 5 * 14.6e9 / 157.3e12) < 1e-9 and abs(t_hbm - 1.07e9 / 6.29e12) < 1e-9
+    # bf16 mode: the same fields against the dense bf16 MFMA peak -- the r04 cars line carried 2.052 here because the
+    # f32 peak was used whatever the precision.  The dominant kernel of that run: 22.6 GFLOP executed and algorithmic, 0.07 ms, 0.19 GB
+    conv = {"name": "c", "ms": 0.070, "launches": 1, "flops": 22.6e9, "alg_flops": 22.6e9, "bytes": 0.19e9}
+    r = bench.roofline_of(conv, "bf16", None)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.3 < r["frac"] < 0.4 and r["mfma_peak_tflops"] == 2500.0
+    for key in ("frac", "executed_frac_of_mfma_peak", "algorithmic_frac", "hbm_frac"):
+        assert 0.0 <= r[key] <= 1.0, (key, r[key])
+    assert abs(r["executed_frac_of_mfma_peak"] - 22.6e9 / 0.070e-3 / 2500e12) < 1e-3
+    t_mfma, t_hbm = bench.roof_seconds([conv], "bf16")
+    assert t_mfma == 0.0 and abs(t_hbm - 0.19e9 / 6.29e12) < 1e-12
+
+
+def test_bench_timed_loop_repeats_and_median():
+    """one warm-up, then R regions of exactly K steps each between two fences; dt_local is the median region."""
+    import bench
+
+    class Gat:
+        depth = 2
+        def wait(self, slot): pass
+        def buffers(self, slot): return (None, None)
+        def submit(self, slot): pass
+        def wait_all(self): pass
+    calls = []
+    loop = bench.TimedLoop(lambda out: calls.append(1), Gat(), 1, "cpu", False, sync=lambda: calls.append("fence"))
+    t = loop.run(2, 3, 5)
+    assert calls.count(1) == 2 + 3 * 5 and calls.count("fence") == 1 + 5
+    assert len(t["dts_local"]) == 5 and t["dt_local"] == sorted(t["dts_local"])[2]
+    assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0]) == 4.0
 
 
 def test_generate_devices_single_process():

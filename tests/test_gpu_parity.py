@@ -156,15 +156,41 @@ def test_error_paths(torch_cuda):
 
 @pytest.mark.parametrize("gan,batch", [("bedrooms", 3), ("cars", 1), ("ffhq", 1)])
 def test_full_size_bit_exact(torch_cuda, oracle_lib, gan, batch):
-    """BASELINE.json full-size configurations (synthetic weights) against the C oracle."""
-    from tests.common import gan_setup
+    """BASELINE.json full-size configurations (synthetic weights) against the C oracle: the u8 pairs of the fused path AND
+    (round 5) every FP32 tensor of the two-call path -- rgb, all features, logits through
+    gsa_generator_forward / gsa_decoder_forward, i.e. through the NCHW export / import kernels at full size (32 % of the u8
+    image values of the synthetic-weights ffhq sample are saturated: the u8 projection alone could hide an error below 1e-3).
+    Batch 1 of ffhq / cars also equals the committed digests of tests/golden/bench_outputs.json (make_bench_hash.py)."""
+    import hashlib
+    from tests.common import gan_setup, golden_bench_outputs
     gcfg, gp, dcfg, dp, z, noise = gan_setup(gan, batch)
     gen = _build(gcfg, gp, dcfg, dp, batch)
     img, mask = gen.generate_batch(z, noise)
-    img_o, mask_o = oracle_lib.Oracle(gcfg, gp, dcfg, dp).generate(z, noise)
+    o = oracle_lib.Oracle(gcfg, gp, dcfg, dp)
+    rgb_o, img_o, feats_o = o.generator(z, noise)
+    logits_o, mask_o = o.decoder(feats_o)
     assert_same(img.cpu().numpy(), img_o, "%s image" % gan)
     assert_same(mask.cpu().numpy(), mask_o, "%s mask" % gan)
     assert 0.001 < mask_o.mean() < 0.999                     # the mask is not degenerate
+    rgb, feats, img2 = gen.netG(z, noise=noise, want_image=True)
+    assert_same(img2.cpu().numpy(), img_o, "%s image (two-call path)" % gan)
+    assert_same(rgb.cpu().numpy(), rgb_o, "%s fp32 rgb" % gan)
+    feats_np = [f.cpu().numpy() for f in feats]
+    for i, (a, b) in enumerate(zip(feats_np, feats_o)):
+        assert_same(a, b, "%s fp32 feature %d" % (gan, i))
+    logits, mask2 = gen._decoder(*feats, want_mask=True)
+    logits_np = logits.cpu().numpy()
+    assert_same(logits_np, logits_o, "%s fp32 logits" % gan)
+    assert_same(mask2.cpu().numpy(), mask_o, "%s mask (two-call path)" % gan)
+    want = golden_bench_outputs().get("%s_b%d_fp32" % (gan, batch))
+    if gan in ("ffhq", "cars"):
+        assert want is not None, "tests/golden/bench_outputs.json lacks the fp32 digests of %s" % gan
+
+        def h(a):
+            return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        assert h(rgb.cpu().numpy()) == want["rgb_f32"] and h(logits_np) == want["logits_f32"]
+        assert h(feats_np[-1]) == want["feature_last_f32"] and h(feats_np[-2]) == want["feature_second_last_f32"]
+        assert h(img.cpu().numpy()) == want["image_u8"] and h(mask.cpu().numpy()) == want["mask_u8"]
 
 
 def test_cli_generate_writes_dataset(torch_cuda, tmp_path):
@@ -638,6 +664,10 @@ def test_device_side_checks_are_reported(torch_cuda, oracle_lib, monkeypatch):
     monkeypatch.setenv("GSA_FAULT", "1")            # the environment arms nothing any more (round 4): only the explicit call does
     bad = _build(gcfg, gp, dcfg, dp, 2)
     monkeypatch.delenv("GSA_FAULT")
+    monkeypatch.delenv("GSA_TEST_HOOKS")            # round 5: and the explicit call alone neither -- it needs GSA_TEST_HOOKS=1 as well
+    with pytest.raises(GsaError, match="test hooks are off"):
+        bad.netG._model.ctx.debug_inject(1)
+    monkeypatch.setenv("GSA_TEST_HOOKS", "1")
     bad.netG._model.ctx.debug_inject(1)
     with pytest.raises(GsaError, match="mapping network timed out"):
         bad.generate_batch(z, noise)                 # the shim checks after a context's first step
@@ -743,6 +773,20 @@ def test_graph_replay_after_a_failed_pass_is_still_bit_exact(torch_cuda, oracle_
         assert_same(mask.cpu().numpy(), mask_o, "mask, call %d after the failed passes" % it)
     assert gen.graphs_captured() == 2
     model.ctx.check()
+
+
+def test_status_snapshot_with_an_idle_replica(torch_cuda):
+    """ImageGenerator(gpu_ids=[a, b]) with ONE sample -- split_sizes drops the empty slice, so the second
+    replica never reserved a workspace -- must still answer snapshot_status() (main.py generate calls it for every batch): the
+    idle replica reports {0, 0}.  (Two contexts on device 0, as in test_in_process_device_list.)"""
+    gcfg, gp, dcfg, dp, z, noise = reduced_setup(7, batch=1)
+    from gan_segmentation_amd.image_generator import ImageGenerator
+    gen = ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[0, 0], batch_size=2)
+    img, mask = gen.generate_batch(z, noise)
+    views = gen.snapshot_status()
+    torch_cuda.cuda.synchronize()
+    assert len(views) == 2 and all(int(v[0]) == 0 and int(v[1]) == 0 for v in views)
+    assert img.shape[0] == 1 and mask.shape[0] == 1
 
 
 def test_cli_generate_stops_at_the_first_bad_batch(torch_cuda, tmp_path, monkeypatch, capsys):
