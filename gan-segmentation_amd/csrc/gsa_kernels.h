@@ -95,6 +95,9 @@ hipError_t launch_wino_lean(const ConvParams& p, int epi, int n, hipStream_t s);
 hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);   // deconv4x4s2 / sub-pixel up+conv
 bool subpixel_uses_wino(const ConvParams& p);                      // true: Winograd F(2x2,2x2) form (static rule: fp32 mode): 9 products per 2x2 class outputs instead of 163x3
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s);
+// gsa_post_lean.hip (round 5): post_rows_kernel<4> in packed fp32 arithmetic (same bits).  GSA_POST_PK: 0 = off, 1 = packed (default), 2 = + non-temporal stores
+int post_pk_mode();
+hipError_t launch_post_pk(const PostParams& q, dim3 grid, size_t lds, hipStream_t s);
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);
 bool conv_fuses_finalize(const ConvParams& p, int epi, bool shortcut);   // true: launch_conv3x3 writes the layer's AdaIN coefficients itself when p.fin_aff is set (whole-plane K-split tiles)
 bool post_fuses_finalize(const PostParams& p);      // true: launch_post_fin does the post pass AND the finalize of this plane in one launch (planes <= 32 x 32)

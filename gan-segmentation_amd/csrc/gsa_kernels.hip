@@ -21,6 +21,7 @@
 //   torgb_kernel    toRGB + _transform_gan_back         networks_stylegan.py:118-126; image_generator.py:76-84
 //   final_conv      final Conv2D + argmax               networks_seg.py:91-92; seg_solver.py:326
 #include "gsa_kernels.h"
+#include "gsa_dev.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -51,12 +52,6 @@
 
 namespace gsa {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
 // Diagnostic build only (make stamp): s_memtime stamps at the phase boundaries of the conv
 // kernel, summed per phase into ConvParams::stamps.  No stamp executes in the product build.
 #ifdef GSA_STAMP
@@ -77,67 +72,6 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define STAMP_DECL do {} while (0)
 #define STAMP_FLUSH(nph) do {} while (0)
 #endif
-
-// LeakyReLU(0.2): max(v, 0.2*v) is the same value bit for bit as (v > 0 ? v : 0.2*v) -- v > 0 gives v > 0.2v,
-// v < 0 gives 0.2v > v, +-0 and NaN map to themselves -- and is one VALU instruction shorter
-__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }
-
-// rint(v * scale) as a wrapping 64-bit integer (1.5*2^52 magic constant); order-independent sums
-__device__ __forceinline__ unsigned long long to_fixed(float v, double scale) {
-    const double magic = 6755399441055744.0;
-    double t = fma((double)v, scale, magic);
-    return (unsigned long long)__double_as_longlong(t) - (unsigned long long)__double_as_longlong(magic);
-}
-
-// Fixed-point sums of squares (round 4; gsa_kernels.h): the unit is 2^-S2 with S2 = clamp(40 - ceil(log2(H*W)), 20, 26), a static
-// function of the plane size -- fine enough on small planes that E[x^2] - mean^2 survives the cancellation when a plane's values
-// sit on a bias far above their spread, coarse enough at 1024^2 that the 64-bit sum holds rms(x) < 2.9e3.  A quad whose sum of
-// squares would not fit the 1.5*2^52 conversion at that unit (q >= 2^(50-S2)) is rounded at 2^-20 instead and shifted into the
-// unit: every term stays an integer multiple of 2^-S2 and a pure function of q, so the sum is order-independent as before, and the
-// per-value range stays |x| < 2.3e4 at every plane size.  S2 is wave-uniform (scalar registers).
-__device__ __forceinline__ int stat_s2(int HW) {
-    const int s2 = 40 - (HW > 1 ? 32 - __builtin_clz((unsigned)HW - 1u) : 0);
-    return s2 < 20 ? 20 : (s2 > 26 ? 26 : s2);
-}
-__device__ __forceinline__ double stat_scale2(int HW) { return __hiloint2double((1023 + stat_s2(HW)) << 20, 0); }
-__device__ __forceinline__ unsigned long long to_fixed_sq(float q, int s2) {
-    // pre-scaling a big q by the exact power of two 2^-(S2-20) and shifting the integer back IS rounding it at 2^-20; the
-    // conversion itself keeps its wave-uniform scale (one scalar register pair), only the mask and two selects are per lane
-    const bool big = q >= __int_as_float((127 + 50 - s2) << 23);
-    const float qs = big ? q * __int_as_float((127 + 20 - s2) << 23) : q;
-    const unsigned long long k = to_fixed(qs, __hiloint2double((1023 + s2) << 20, 0));
-    return k << (big ? s2 - 20 : 0);
-}
-
-// value of another lane of the same aligned quad (DPP quad_perm, no LDS traffic)
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));   // quad_perm: every lane has a source
-}
-
-// 4x4 transpose across the four lanes of an aligned quad (two DPP butterfly steps, no LDS): lane j
-// enters with M[r][j] in register r and leaves with M[j][r].  The MFMA C layout (lane = channel,
-// register = x) becomes (lane = x, registers = 4 consecutive channels): one 16-byte access per lane
-// instead of four dword accesses, and the 16 lanes of a patch row cover 4 whole pixels.
-__device__ __forceinline__ f32x4 quad_transpose(float v0, float v1, float v2, float v3, int j) {
-    const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0;
-    float pa = dpp_quad<0xB1>(v0), pb = dpp_quad<0xB1>(v1);
-    const float a0 = b0 ? pb : v0, a1 = b0 ? v1 : pa;
-    pa = dpp_quad<0xB1>(v2); pb = dpp_quad<0xB1>(v3);
-    const float a2 = b0 ? pb : v2, a3 = b0 ? v3 : pa;
-    pa = dpp_quad<0x4E>(a0); pb = dpp_quad<0x4E>(a2);
-    const float c0 = b1 ? pb : a0, c2 = b1 ? a2 : pa;
-    pa = dpp_quad<0x4E>(a1); pb = dpp_quad<0x4E>(a3);
-    const float c1 = b1 ? pb : a1, c3 = b1 ? a3 : pa;
-    return f32x4{c0, c1, c2, c3};
-}
-
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl_xor(lo, m);
-    hi = __shfl_xor(hi, m);
-    return ((unsigned long long)hi << 32) | lo;
-}
 
 // ------------------------------------------------------------------------------------------
 // Shared pieces of the two MFMA convolutions.
@@ -335,15 +269,6 @@ __device__ __forceinline__ void store_chunk(float* sA, const f32x4& v, const f32
 // in-kernel stamps showed 57k-cycle load phases and 7x-stretched MFMA phases on the 16-channel
 // layers.)
 struct WorkTile { int n, g, y0, x0, row; };   // row = tile index inside the image
-constexpr int kDirectRows = 64;               // accumulator rows per sample of the "direct statistics" form (power of two)
-
-// Workgroups are dispatched round-robin over the 8 XCDs (workgroup i -> XCD i % 8) and each XCD has its own L2.
-// Persistent kernels therefore hand XCD x the x-th contiguous eighth of the work: the vertical neighbours of a
-// tile (one image row of tiles further on) are then processed on the same XCD at about the same time, and the
-// halo rows they share are served by that L2 instead of being fetched from HBM once per XCD.
-__device__ __forceinline__ int xcd_block(int b, int nb) {
-    return (nb & 7) == 0 && !GSA_NO_XCD_REMAP ? (b & 7) * (nb >> 3) + (b >> 3) : b;
-}
 
 //
 // BF = bf16 MFMA mode (BASELINE config 5): operands are rounded to bf16 when they are staged (inputs after
@@ -1127,54 +1052,7 @@ __global__ __launch_bounds__(256 * PS) void conv3x3_ksplit(ConvParams p) {
 // own MFMA -- into four v_add_f32 / v_sub_f32 (and folds every other spelling of the subtraction back into one), so the
 // instruction is written out.  f32 MFMAs and vector-ALU instructions share the SIMD's issue time:
 // every instruction saved is MFMA time gained.
-// Hazards: the compiler's hazard recognizer does not see through inline asm, so the two software-managed ones are handled
-// here.  A vector-ALU result needs 2 wait states before an MFMA reads it as an operand: the transformed patch goes through
-// valu_settle() (s_nop 1 with the four vectors of a frequency row as in/out operands) before the MFMAs of that row.  An MFMA RESULT needs 11 wait
-// states after an 8-pass MFMA before a vector-ALU instruction reads it: the accumulators go through mfma_settle() before the
-// first packed add.  (The waits for the LDS reads feeding an asm are inserted by the compiler from its register operands.)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) {
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) {
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ f32x2 fma2v(f32x2 a, f32x2 m, f32x2 b) {      // fmaf(a, m, b) per component (IEEE fused: the same bits as fmaf)
-    f32x2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(m), "v"(b));
-    return r;
-}
-__device__ __forceinline__ f32x4 add4(const f32x4& a, const f32x4& b) {
-    const f32x2 lo = pk_add2(a.xy, b.xy), hi = pk_add2(a.zw, b.zw);
-    return f32x4{lo.x, lo.y, hi.x, hi.y};
-}
-__device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) {
-    const f32x2 lo = pk_sub2(a.xy, b.xy), hi = pk_sub2(a.zw, b.zw);
-    return f32x4{lo.x, lo.y, hi.x, hi.y};
-}
-__device__ __forceinline__ void valu_settle(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
-    asm("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));      // not volatile: ordered by its operands only
-}
-// 12 wait states with the sixteen accumulators of one output-channel tile as in/out operands: every later read of them is
-// ordered behind it
-__device__ __forceinline__ void mfma_settle(f32x4 (&a)[16]) {
-    asm("s_nop 7\n\ts_nop 3"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
-                   "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
-}
-
-// ------------------------------------------------------------------------------------------
-// conv3x3 (pad 1, stride 1, one source) in WINOGRAD F(2x2, 3x3) form on v_mfma_f32_16x16x4_f32.
-//
-//     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A      per 2x2 output tile: 16 products per (tile, c, o) instead of 36
-//
-// The sixteen "frequencies" f = 4i+j are sixteen independent GEMMs  M_f[tile][o] = sum_c V_f[tile][c] U_f[c][o]:
-// M = 16 Winograd tiles, N = 16 output channels, K = input channels -- 64 MFMAs per 16-channel block and 64 output
-// pixels where the direct form needs 144.  Canonical arithmetic: oracle/c/gsa_oracle.c conv3x3_wino (the transforms
+// Hazards: the compiler's hazard recot form needs 144.  Canonical arithmetic: oracle/c/gsa_oracle.c conv3x3_wino (the transforms
 // are plain fp32 adds in a fixed order, each M_f is one k-ordered fmaf chain = the MFMA, U is computed in double on
 // the host and rounded once), so the result is reproduced BIT FOR BIT; DESIGN.md states the rule that selects the
 // form (layer shape only: plain 3x3 convs with outputs >= 32 px, fp32 mode).
@@ -4285,10 +4163,7 @@ static int wino_tw(const ConvParams& p) {
 }
 
 static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s) {
-    if (wino_lean_applies(p, epi)) {
-        if (p.stat_rows_host) *p.stat_rows_host = 0;
-        return launch_wino_lean(p, epi, n, s);
-    }
+    if (wino_lean_applies(p, epi)) return launch_wino_lean(p, epi, n, s);
     if (wino_dma(p, epi) && wino_nt(p) == 1) return launch_wino_dma(p, epi, n, s);
     if (wino_tw(p) == 2) {
         if (epi == EPI_SYNTH) return p.aff0 ? launch_wino_t<EPI_SYNTH, 1, false, true, 1, 2>(p, n, s) : launch_wino_t<EPI_SYNTH, 1, false, false, 1, 2>(p, n, s);
@@ -4609,6 +4484,9 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
     q.row_groups = post_row_groups(p);
     dim3 grid(post_blocks(p), n);
     const size_t lds = sizeof(unsigned long long) * 2 * p.C;
+    // the packed-arithmetic form (gsa_post_lean.hip): fp32, four rows per thread, a wave's 64 threads inside one row group
+    if (rpt == 4 && !p.bf16 && post_pk_mode() > 0 && ((p.W / 4) * (p.C / 4)) % 64 == 0)
+        return launch_post_pk(q, grid, lds + sizeof(float) * 9 * p.C, s);
 #define GSA_POST(BF) \
     if (rpt == 8) hipLaunchKernelGGL((post_rows_kernel<8, BF>), grid, dim3(256), lds, s, q); \
     else if (rpt == 4) hipLaunchKernelGGL((post_rows_kernel<4, BF>), grid, dim3(256), lds, s, q); \

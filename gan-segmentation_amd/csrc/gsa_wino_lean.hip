@@ -21,133 +21,124 @@
 //     per-channel constants are packed pairs, bias / BatchNorm / LeakyReLU run as packed operations;
 //   * the first MFMA of every chain starts from the inline constant 0: the accumulators are never cleared.
 #include "gsa_kernels.h"
+#include "gsa_dev.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 namespace gsa {
 namespace lean {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int LH = 18, LW = 18, RS = LW * 16 + 4;      // halo image: 18 rows of 18 pixels x 16 channels, row stride 292 floats (bank-conflict free patch reads)
 constexpr int IMG = LH * RS;                           // floats per image buffer (21 KB)
 constexpr int SEG = 16 * 256;                          // U floats of the (16 couts, 16 channels) panel: [f][kq][16][cg]
 constexpr int NPIX = LH * LW;                          // 324 halo pixels = 1296 chunks = 5 rounds of 256 threads + 16 chunks
 
-__device__ __forceinline__ int xcd_block(int b, int nb) { return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b; }
-
-// packed fp32 operations (IEEE, the same bits as the scalar forms); hazards towards / from MFMAs are settled by hand below
-__device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ f32x2 pk_fma2(f32x2 a, f32x2 m, f32x2 b) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(m), "v"(b)); return r; }
-__device__ __forceinline__ f32x2 pk_mul2(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ f32x4 add4(const f32x4& a, const f32x4& b) { const f32x2 lo = pk_add2(a.xy, b.xy), hi = pk_add2(a.zw, b.zw); return f32x4{lo.x, lo.y, hi.x, hi.y}; }
-__device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) { const f32x2 lo = pk_sub2(a.xy, b.xy), hi = pk_sub2(a.zw, b.zw); return f32x4{lo.x, lo.y, hi.x, hi.y}; }
-__device__ __forceinline__ f32x4 fma4(const f32x4& a, const f32x4& m, const f32x4& b) {
-    const f32x2 lo = pk_fma2(a.xy, m.xy, b.xy), hi = pk_fma2(a.zw, m.zw, b.zw);
-    return f32x4{lo.x, lo.y, hi.x, hi.y};
-}
-// LeakyReLU(0.2) = max(v, 0.2 v) (gsa_kernels.hip lrelu: the same bits as the select form)
-__device__ __forceinline__ f32x4 lrelu4(const f32x4& v, f32x2 k02) {
-    const f32x2 lo = pk_mul2(v.xy, k02), hi = pk_mul2(v.zw, k02);
-    return f32x4{fmaxf(v.x, lo.x), fmaxf(v.y, lo.y), fmaxf(v.z, hi.x), fmaxf(v.w, hi.y)};
-}
-// 2 wait states between a vector-ALU result and the MFMA that reads it (the hazard recognizer does not see through inline asm)
-__device__ __forceinline__ void valu_settle(f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
-// 11 wait states between an 8-pass MFMA result and a vector-ALU read of it
-__device__ __forceinline__ void mfma_settle(f32x4 (&a)[16]) {
-    asm("s_nop 7\n\ts_nop 3"
-        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
-          "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
-}
-
 struct Tile { int n, y0, x0; };
 
-// EPI_DEC: y = lrelu(fmaf(v, bn_s, bn_beta)) [+ residual at half resolution (RES)];  AFF: the source carries AdaIN coefficients.
-template <int EPI, bool AFF, bool RES>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_c16(ConvParams p) {
+// EPI_DEC: y = lrelu(fmaf(v, bn_s, bn_beta)) [+ residual at half resolution (RES)];  EPI_SYNTH: y = lrelu((v + nscale * noise) + nbias) and the
+// instance-norm statistics of y (direct form: per-wave integer sums, one atomic per channel and sample range);  AFF: the source carries AdaIN coefficients.
+// NB = 16-channel input blocks (1: 16 input channels, 2: 32), GW = 16-channel output groups per workgroup = all of the layer's (1: 16 output
+// channels, 4 waves; 2: 32, 8 waves -- waves 0-3 / 4-7 multiply the SAME staged image by the two groups' panels, as conv3x3_wino<..., GW = 2>).
+// An item is (tile, block); the accumulators live across the NB items of a tile, the last one ends in the epilogue.
+// DB = false (NB = 1, GW = 1 only): ONE image buffer and two barriers per item -- the patch is read and transformed into registers, then the
+// buffer is refilled with the next item while the MFMAs run out of registers: 37 KB of LDS per workgroup, so THREE workgroups per CU when
+// the kernel also fits 168 registers (more waves instead of bigger items).
+template <int EPI, bool AFF, bool RES, int NB, int GW, bool DB = true>
+__global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_wino_lean(ConvParams p) {
+    static_assert(DB || (NB == 1 && GW == 1), "single-buffered form: one block, one group");
+    constexpr int NTHR = 256 * GW, CIN = 16 * NB, COUT = 16 * GW;
+    constexpr int NCH = (NPIX * 4 + NTHR - 1) / NTHR;      // staging rounds per item: 6 (5 full + 16 chunks) with 256 threads, 3 (2 full + 272) with 512
+    constexpr bool kLastPartial = (NPIX * 4) % NTHR != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const sA = smem;                 // [2][IMG]
-    float* const sB = smem + 2 * IMG;       // [SEG]
+    float* const sA = smem;                 // [DB ? 2 : 1][IMG]
+    float* const sB = smem + (DB ? 2 : 1) * IMG;       // [GW][NB][SEG]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, gsel = wave8 >> 2;
     const int i16 = lane & 15, kq = lane >> 4, part = tid & 3;
     const int H = p.H, W = p.W;
     const int per = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int w_begin = xcd_block(blockIdx.x, gridDim.x) * per;
     const int w_end = min(p.total_tiles, w_begin + per);
     if (w_begin >= w_end) return;
-    const int items = w_end - w_begin;
+    const int items = (w_end - w_begin) * NB;
 
-    {   // the 16 KB weight panel, once
+    {   // the whole weight panel of the layer ([Cout/16][Cin/16][SEG], 16 KB per (group, block)), once
         const f32x4* src = reinterpret_cast<const f32x4*>(p.wpk);
         f32x4 r[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = src[tid + 256 * j];
+        for (int h = 0; h < NB; ++h) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) reinterpret_cast<f32x4*>(sB)[tid + 256 * j] = r[j];
+            for (int j = 0; j < 4; ++j) r[j] = src[tid + NTHR * (4 * h + j)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) reinterpret_cast<f32x4*>(sB)[tid + NTHR * (4 * h + j)] = r[j];
+        }
     }
 
-    // ---- staging: chunk q = tid + 256 k = (halo pixel q >> 2, channels 4 * part ..); byte offsets from the halo origin
-    unsigned s_off[6], eflags = 0;
-    int l_off[6];
+    // ---- staging: chunk q = tid + NTHR k = (halo pixel q >> 2, channels 4 * part .. of the item's block); byte offsets from the halo origin
+    unsigned s_off[NCH], eflags = 0;
+    int l_off[NCH];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int pix = (tid + 256 * k) >> 2;
+    for (int k = 0; k < NCH; ++k) {
+        const int pix = (tid + NTHR * k) >> 2;
         const bool real = pix < NPIX;
         const int ly = real ? pix / LW : 1, lx = real ? pix % LW : 1;
-        s_off[k] = (unsigned)(((ly * W + lx) * 16 + part * 4) * 4);
+        s_off[k] = (unsigned)(((ly * W + lx) * CIN + part * 4) * 4);
         l_off[k] = real ? ly * RS + lx * 16 + part * 4 : -1;
         eflags |= (unsigned)((ly == 0 ? 1 : 0) | (ly == LH - 1 ? 2 : 0) | (lx == 0 ? 4 : 0) | (lx == LW - 1 ? 8 : 0)) << (4 * k);
     }
-    const unsigned safe_off = (unsigned)((((W + 1) * 16) + part * 4) * 4);      // the tile's own first pixel: always inside the image
+    const unsigned safe_off = (unsigned)((((W + 1) * CIN) + part * 4) * 4);      // the tile's own first pixel: always inside the image
     auto edge_code = [&](const Tile& t) { return (t.y0 == 0 ? 1 : 0) | (t.y0 + 16 == H ? 2 : 0) | (t.x0 == 0 ? 4 : 0) | (t.x0 + 16 == W ? 8 : 0); };
     auto advance = [&](Tile& t) { t.x0 += 16; if (t.x0 == W) { t.x0 = 0; t.y0 += 16; if (t.y0 == H) { t.y0 = 0; t.n += 1; } } };
 
-    f32x4 ra[6];                              // the item in flight (loaded, not yet written to LDS)
-    f32x4 cA, cB, nA, nB;                     // AdaIN A / B of this thread's four channels: current sample, sample of the item in flight
-    cA = cB = nA = nB = f32x4{0.f, 0.f, 0.f, 0.f};
-    int n_coef = -1, n_next = -1;
-    auto load_item = [&](const Tile& t, int e) {
-        const char* hb = reinterpret_cast<const char*>(p.src0) + (((long)(t.n * H + t.y0) * W + t.x0) - (W + 1)) * 64;
-        // round 5 holds 16 real chunks (lanes 0..15 of wave 0); everybody issues it -- the idle lanes read the tile's first pixel
+    f32x4 ra[NCH];                            // the item in flight (loaded, not yet written to LDS)
+    f32x4 cA[NB], cB[NB];                     // AdaIN A / B of this thread's four channels of every block, for the sample being staged
+#pragma unroll
+    for (int h = 0; h < NB; ++h) cA[h] = cB[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int n_coef = -1;
+    auto load_item = [&](const Tile& t, int e, int cb) {
+        const char* hb = reinterpret_cast<const char*>(p.src0) + ((((long)(t.n * H + t.y0) * W + t.x0) - (W + 1)) * CIN + cb * 16) * 4;
+        // the last round holds fewer real chunks than threads; everybody issues it -- the idle lanes read the tile's first pixel
         if (e) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < NCH; ++k) {
                 const unsigned bad = (eflags >> (4 * k)) & (unsigned)e;
                 const unsigned off = s_off[k] + (bad ? safe_off - s_off[k] : 0u);
                 ra[k] = *reinterpret_cast<const f32x4*>(hb + off);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) ra[k] = *reinterpret_cast<const f32x4*>(hb + s_off[k]);
-        }
-        if (AFF && t.n != n_next) {           // wave-uniform: first item and sample changes
-            const f32x4* a = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * 16 + part * 4);      // (mean, A, B, -) x 4
-            const f32x4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
-            nA = f32x4{a0[1], a1[1], a2[1], a3[1]};
-            nB = f32x4{a0[2], a1[2], a2[2], a3[2]};
-            n_next = t.n;
+            for (int k = 0; k < NCH; ++k) ra[k] = *reinterpret_cast<const f32x4*>(hb + s_off[k]);
         }
     };
-    auto write_item = [&](const Tile& t, int e, int buf) {
+    auto write_item = [&](const Tile& t, int e, int cb, int buf) {
         float* img = sA + buf * IMG;
-        if (AFF && t.n != n_coef) { cA = nA; cB = nB; n_coef = t.n; }
+        if (AFF && t.n != n_coef) {           // wave-uniform: the first item and sample changes (a workgroup's range spans at most a few samples)
+#pragma unroll
+            for (int h = 0; h < NB; ++h) {
+                const f32x4* a = reinterpret_cast<const f32x4*>(p.aff0 + (size_t)t.n * CIN + h * 16 + part * 4);      // (mean, A, B, -) x 4
+                const f32x4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+                cA[h] = f32x4{a0[1], a1[1], a2[1], a3[1]};
+                cB[h] = f32x4{a0[2], a1[2], a2[2], a3[2]};
+            }
+            n_coef = t.n;
+        }
+        const f32x4 kA = NB == 1 || cb == 0 ? cA[0] : cA[NB - 1], kB = NB == 1 || cb == 0 ? cB[0] : cB[NB - 1];
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         if (e) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const f32x4 v = AFF ? fma4(ra[k], cA, cB) : ra[k];
+            for (int k = 0; k < NCH; ++k) {
+                const f32x4 v = AFF ? fma4(ra[k], kA, kB) : ra[k];
                 const bool bad = ((eflags >> (4 * k)) & (unsigned)e) != 0;
-                if (k < 5 || l_off[5] >= 0) *reinterpret_cast<f32x4*>(img + l_off[k]) = bad ? z : v;
+                if (!kLastPartial || k < NCH - 1 || l_off[NCH - 1] >= 0) *reinterpret_cast<f32x4*>(img + l_off[k]) = bad ? z : v;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if (k < 5 || l_off[5] >= 0) *reinterpret_cast<f32x4*>(img + l_off[k]) = AFF ? fma4(ra[k], cA, cB) : ra[k];
+            for (int k = 0; k < NCH; ++k)
+                if (!kLastPartial || k < NCH - 1 || l_off[NCH - 1] >= 0) *reinterpret_cast<f32x4*>(img + l_off[k]) = AFF ? fma4(ra[k], kA, kB) : ra[k];
         }
     };
 
@@ -155,29 +146,352 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_c16(ConvParams p) {
     const int wty = ((i16 >> 3) & 1) * 2 + ((i16 >> 1) & 1), wtx = ((i16 >> 2) & 1) * 2 + (i16 & 1);
     const int qy = wave >> 1, qx = wave & 1;
     const int pbase = (qy * 8 + 2 * wty) * RS + (qx * 8 + 2 * wtx) * 16 + kq * 4;
-    const int bbase = (kq * 16 + i16) * 4;
-    // ---- epilogue: the lane's tile = output pixels (2 wty + i, 2 wtx + j) of the quadrant, channels 4 kq .. 4 kq + 3
-    const unsigned out_off = (unsigned)((((qy * 8 + 2 * wty) * W + qx * 8 + 2 * wtx) * 16 + kq * 4) * 4);      // bytes from the tile origin
-    const unsigned res_off = RES ? (unsigned)((((qy * 4 + wty) * (W >> 1) + qx * 4 + wtx) * 16 + kq * 4) * 4) : 0u;
+    const int bbase = gsel * (NB * SEG) + (kq * 16 + i16) * 4;
+    // ---- epilogue: the lane's tile = output pixels (2 wty + i, 2 wtx + j) of the quadrant, channels 16 gsel + 4 kq .. + 3
+    const int co4 = gsel * 16 + kq * 4;
+    const unsigned out_off = (unsigned)((((qy * 8 + 2 * wty) * W + qx * 8 + 2 * wtx) * COUT + co4) * 4);      // bytes from the tile origin
+    const unsigned res_off = RES ? (unsigned)((((qy * 4 + wty) * (W >> 1) + qx * 4 + wtx) * COUT + co4) * 4) : 0u;
     f32x4 e2 = {0.f, 0.f, 0.f, 0.f}, e3 = e2;
     if (EPI == EPI_DEC) {
-        e2 = *reinterpret_cast<const f32x4*>(p.bn_s + kq * 4);
-        e3 = *reinterpret_cast<const f32x4*>(p.bn_beta + kq * 4);
+        e2 = *reinterpret_cast<const f32x4*>(p.bn_s + co4);
+        e3 = *reinterpret_cast<const f32x4*>(p.bn_beta + co4);
     }
+    // EPI_SYNTH: v = lrelu((v + nscale * noise) + nbias), then the instance-norm statistics of the stored values
+    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0;
+    if (EPI == EPI_SYNTH) {
+        e0 = *reinterpret_cast<const f32x4*>(p.nscale + co4);
+        e1 = *reinterpret_cast<const f32x4*>(p.nbias + co4);
+    }
+    const unsigned nz_off = (unsigned)((((qy * 8 + 2 * wty) * W + qx * 8 + 2 * wtx)) * 4);      // bytes from the tile origin in the (N, 1, H, W) noise plane
+    f32x2 nz[2] = {{0.f, 0.f}, {0.f, 0.f}};                                                       // noise of tile row i at x = 2 wtx, 2 wtx + 1
+    const int s2 = stat_s2(H * W);
+    const bool odd = (lane & 1) != 0;
+    unsigned long long dI1[4] = {0ull, 0ull, 0ull, 0ull}, dI2[4] = {0ull, 0ull, 0ull, 0ull};      // direct statistics of the lane's four channels
+    auto flush_stats = [&](int n) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned long long I1 = dI1[c], I2 = dI2[c];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { I1 += shfl_xor_u64(I1, m); I2 += shfl_xor_u64(I2, m); }
+            if (i16 == 0) {
+                StatPart* a = p.partials + ((size_t)n * p.prow + (blockIdx.x & (kDirectRows - 1))) * COUT + co4 + c;
+                atomicAdd(&a->s1, I1);
+                atomicAdd(&a->s2, I2);
+            }
+            dI1[c] = dI2[c] = 0ull;
+        }
+    };
     const f32x2 k02 = {0.2f, 0.2f};
     f32x4 rr = {0.f, 0.f, 0.f, 0.f};
     auto epilogue_loads = [&](const Tile& t) {
+        if (EPI == EPI_SYNTH) {
+            const char* nb = reinterpret_cast<const char*>(p.noise) + ((long)(t.n * H + t.y0) * W + t.x0) * 4;
+            nz[0] = *reinterpret_cast<const f32x2*>(nb + nz_off);
+            nz[1] = *reinterpret_cast<const f32x2*>(nb + (long)W * 4 + nz_off);
+        }
         if (RES) {
-            const char* rb = reinterpret_cast<const char*>(p.resid) + ((long)(t.n * (H >> 1) + (t.y0 >> 1)) * (W >> 1) + (t.x0 >> 1)) * 64;
+            const char* rb = reinterpret_cast<const char*>(p.resid) + ((long)(t.n * (H >> 1) + (t.y0 >> 1)) * (W >> 1) + (t.x0 >> 1)) * (COUT * 4);
             rr = *reinterpret_cast<const f32x4*>(rb + res_off);
         }
     };
 
-    f32x4 acc[16];
-    auto multiply = [&](int buf) {
+    f32x4 acc[16], V[16];
+    auto transform = [&](int buf) {
         const float* a_img = sA + buf * IMG + pbase;
-        const float* b_img = sB + bbase;
         // input transform V = B^T d B: rows t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3; then the same along the columns
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(a_img + 0 * RS + c * 16);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(a_img + 1 * RS + c * 16);
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(a_img + 2 * RS + c * 16);
+            const f32x4 d3 = *reinterpret_cast<const f32x4*>(a_img + 3 * RS + c * 16);
+            V[0 * 4 + c] = sub4(d0, d2);
+            V[1 * 4 + c] = add4(d1, d2);
+            V[2 * 4 + c] = sub4(d2, d1);
+            V[3 * 4 + c] = sub4(d1, d3);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 t0 = V[i * 4 + 0], t1 = V[i * 4 + 1], t2 = V[i * 4 + 2], t3 = V[i * 4 + 3];
+            V[i * 4 + 0] = sub4(t0, t2);
+            V[i * 4 + 1] = add4(t1, t2);
+            V[i * 4 + 2] = sub4(t2, t1);
+            V[i * 4 + 3] = sub4(t1, t3);
+            valu_settle(V[i * 4 + 0], V[i * 4 + 1], V[i * 4 + 2], V[i * 4 + 3]);
+        }
+    };
+    auto mfmas = [&](auto first_tag, int cb) {
+        constexpr bool FIRST = decltype(first_tag)::value;      // the tile's first block: every chain starts from the inline constant 0
+        const float* b_img = sB + bbase + cb * SEG;
+        // sixteen chains, k ascending (channel 4 kq + cg at k slot kq of MFMA cg); weights = A operand, patch = B operand
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            f32x4 u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = *reinterpret_cast<const f32x4*>(b_img + (fb * 4 + j) * 256);
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = fb * 4 + j;
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][cg], V[f][cg], FIRST && cg == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[f], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto multiply = [&](auto first_tag, int buf, int cb) { transform(buf); mfmas(first_tag, cb); };
+    auto epilogue = [&](const Tile& t) {
+        // output transform Y = A^T M A: rows s0 = (M0 + M1) + M2, s1 = (M1 - M2) - M3, then the same along the columns
+        mfma_settle(acc);
+        f32x4 s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = add4(add4(acc[j], acc[4 + j]), acc[8 + j]);
+            s1[j] = sub4(sub4(acc[4 + j], acc[8 + j]), acc[12 + j]);
+        }
+        f32x4 y[2][2];
+        y[0][0] = add4(add4(s0[0], s0[1]), s0[2]); y[0][1] = sub4(sub4(s0[1], s0[2]), s0[3]);
+        y[1][0] = add4(add4(s1[0], s1[1]), s1[2]); y[1][1] = sub4(sub4(s1[1], s1[2]), s1[3]);
+        char* ob = reinterpret_cast<char*>(p.out) + ((long)(t.n * H + t.y0) * W + t.x0) * (COUT * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = y[i][j];
+                if (EPI == EPI_DEC) {
+                    v = lrelu4(fma4(v, e2, e3), k02);
+                    if (RES) v = add4(rr, v);
+                }
+                if (EPI == EPI_SYNTH) {      // t = nscale * noise (rounded), (v + t) + nbias, LeakyReLU
+                    const f32x2 tlo = j == 0 ? pk_mul2_lo(e0.xy, nz[i]) : pk_mul2_hi(e0.xy, nz[i]);
+                    const f32x2 thi = j == 0 ? pk_mul2_lo(e0.zw, nz[i]) : pk_mul2_hi(e0.zw, nz[i]);
+                    v = lrelu4(add4(add4(v, f32x4{tlo.x, tlo.y, thi.x, thi.y}), e1), k02);
+                    y[i][j] = v;
+                }
+                *reinterpret_cast<f32x4*>(ob + (long)i * W * (COUT * 4) + out_off + j * (COUT * 4)) = v;
+            }
+        if (EPI == EPI_SYNTH) {
+            // Statistics per aligned x-quad and channel: s = (v0 + v1) + (v2 + v3), q = (v0 v0 + v1 v1) + (v2 v2 + v3 v3).  The quad of tile
+            // row i spans this lane's tile (x = 2 wtx, 2 wtx + 1) and its x-neighbour's (lane ^ 1): each lane forms its own pair sums, the
+            // pair exchanges them by DPP, the even lane finishes row 0 and the odd lane row 1 -- a + b = b + a bit for bit, so which lane
+            // adds does not matter; every quad is counted once.
+            f32x4 ps[2], pq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ps[i] = add4(y[i][0], y[i][1]);
+                const f32x2 a0 = pk_mul2(y[i][0].xy, y[i][0].xy), a1 = pk_mul2(y[i][0].zw, y[i][0].zw);
+                const f32x2 b0 = pk_mul2(y[i][1].xy, y[i][1].xy), b1 = pk_mul2(y[i][1].zw, y[i][1].zw);
+                pq[i] = add4(f32x4{a0.x, a0.y, a1.x, a1.y}, f32x4{b0.x, b0.y, b1.x, b1.y});
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float keep_s = odd ? ps[1][c] : ps[0][c], send_s = odd ? ps[0][c] : ps[1][c];
+                const float keep_q = odd ? pq[1][c] : pq[0][c], send_q = odd ? pq[0][c] : pq[1][c];
+                const float sq = keep_s + dpp_quad<0xB1>(send_s);
+                const float qq = keep_q + dpp_quad<0xB1>(send_q);
+                dI1[c] += to_fixed(sq, kStatScale1);
+                dI2[c] += to_fixed_sq(qq, s2);
+            }
+        }
+    };
+
+    // ---- pipeline over the items (tile, block): item `it` is multiplied out of LDS buffer it & 1, item it+1 sits in ra, item it+2 is being loaded
+    Tile tc, tr;
+    {
+        const int tx = w_begin % p.tiles_x, r = w_begin / p.tiles_x;
+        tc.x0 = tx * 16; tc.y0 = (r % p.tiles_y) * 16; tc.n = r / p.tiles_y;
+    }
+    int ec = edge_code(tc), er, cbc = 0, cbr = 0;
+    auto next_item = [&](Tile& t, int& e, int& cb) {
+        if (NB == 1 || ++cb == NB) { cb = 0; advance(t); e = edge_code(t); }
+    };
+    load_item(tc, ec, 0);
+    write_item(tc, ec, 0, 0);
+    tr = tc; er = ec;
+    if (items > 1) { next_item(tr, er, cbr); load_item(tr, er, cbr); }
+    __syncthreads();
+    if constexpr (DB) {
+        for (int it = 0; it < items; ++it) {
+            const bool has_next = it + 1 < items;
+            if (has_next) write_item(tr, er, cbr, (it + 1) & 1);
+            if (cbc == NB - 1) epilogue_loads(tc);
+            Tile t2 = tr; int e2c = er, cb2 = cbr;
+            if (it + 2 < items) { next_item(t2, e2c, cb2); load_item(t2, e2c, cb2); }
+            if (NB == 1 || cbc == 0) multiply(std::true_type{}, it & 1, 0);
+            else multiply(std::false_type{}, it & 1, cbc);
+            if (cbc == NB - 1) {
+                epilogue(tc);
+                if (EPI == EPI_SYNTH && (!has_next || tr.n != tc.n)) flush_stats(tc.n);
+            }
+            __syncthreads();
+            tc = tr; ec = er; cbc = cbr; tr = t2; er = e2c; cbr = cb2;
+        }
+    } else {
+        for (int it = 0; it < items; ++it) {
+            const bool has_next = it + 1 < items;
+            transform(0);                       // the patch of item `it` out of the one buffer, into registers
+            __syncthreads();                    // every wave has read it
+            if (has_next) write_item(tr, er, 0, 0);
+            epilogue_loads(tc);
+            Tile t2 = tr; int e2c = er, cb2 = 0;
+            if (it + 2 < items) { next_item(t2, e2c, cb2); load_item(t2, e2c, cb2); }
+            mfmas(std::true_type{}, 0);
+            epilogue(tc);
+            if (EPI == EPI_SYNTH && (!has_next || tr.n != tc.n)) flush_stats(tc.n);
+            __syncthreads();                    // item it + 1 is complete in the buffer
+            tc = tr; ec = er; tr = t2; er = e2c;
+        }
+    }
+}
+
+// ---- the streamed-weight layers (>= 64 input channels: g.16 ... g.256.conv_2, d.cvt_4 ... 6 of the FFHQ path) in the same lean form ----------
+// One workgroup = 4 waves on 16x16 tiles x ONE 16-channel output group (blockIdx.y), an item = (tile, 16-channel block).  As conv3x3_wino<EPI, 1,
+// true, AFF, 1>: double-buffered image and weight block, activations prefetched two items ahead through registers, accumulators across the
+// blocks of a tile, direct statistics.  What is leaner: the item's 16 KB weight block goes to LDS by LDS-DMA (global_load_lds_dwordx4: four
+// 1 KB pieces per wave, issued one item ahead into the buffer the previous item has left, waited for with a counted vmcnt before the item's
+// closing barrier) -- no staging registers, no LDS stores, and room for the accumulators beside the prefetch; the sample's AdaIN coefficients sit in
+// a 4 KB LDS table as (A x 16 | B x 16) per block -- two LDS reads per item instead of four global loads of (mean, A, B, -) entries -- and are
+// applied with packed fma; wave-uniform global bases; border flags in one word; weights as the A operand, so the epilogue of the tile's last
+// block is the transposition-free packed one of conv3x3_wino_lean; the chains of a tile's first block start from the inline constant 0.
+template <int EPI, bool AFF>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
+    constexpr int NCH = 6;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const sA = smem;                       // [2][IMG]
+    float* const sB = smem + 2 * IMG;             // [2][SEG]
+    float* const sE = sB + 2 * SEG;               // [4][16]: nscale | nbias | bn_s | bn_beta of the group's 16 output channels
+    float* const sC = sE + 64;                    // [nblk][32]: A of the block's 16 channels, then B (the sample being staged)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4, part = tid & 3;
+    const int H = p.H, W = p.W, CIN = p.C0, COUT = p.Cout, nblk = p.C0 >> 4;
+    const int g = blockIdx.y;
+    const int per = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int w_begin = xcd_block(blockIdx.x, gridDim.x) * per;
+    const int w_end = min(p.total_tiles, w_begin + per);
+    if (w_begin >= w_end) return;
+    const int items = (w_end - w_begin) * nblk;
+
+    unsigned s_off[NCH], eflags = 0;
+    int l_off[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int pix = (tid + 256 * k) >> 2;
+        const bool real = pix < NPIX;
+        const int ly = real ? pix / LW : 1, lx = real ? pix % LW : 1;
+        s_off[k] = (unsigned)(((ly * W + lx) * CIN + part * 4) * 4);
+        l_off[k] = real ? ly * RS + lx * 16 + part * 4 : -1;
+        eflags |= (unsigned)((ly == 0 ? 1 : 0) | (ly == LH - 1 ? 2 : 0) | (lx == 0 ? 4 : 0) | (lx == LW - 1 ? 8 : 0)) << (4 * k);
+    }
+    const unsigned safe_off = (unsigned)((((W + 1) * CIN) + part * 4) * 4);
+    auto edge_code = [&](const Tile& t) { return (t.y0 == 0 ? 1 : 0) | (t.y0 + 16 == H ? 2 : 0) | (t.x0 == 0 ? 4 : 0) | (t.x0 + 16 == W ? 8 : 0); };
+    auto advance = [&](Tile& t) { t.x0 += 16; if (t.x0 == W) { t.x0 = 0; t.y0 += 16; if (t.y0 == H) { t.y0 = 0; t.n += 1; } } };
+
+    f32x4 ra[NCH];                                // the item in flight: this thread's activation chunks
+    const float* const wgrp = p.wpk + (size_t)g * nblk * SEG + lane * 4;
+    // the item's weight block: pieces wave, wave + 4, wave + 8, wave + 12 of 1 KB each, straight into the LDS panel
+    auto dma_weights = [&](int cb, int buf) {
+        const float* wb = wgrp + (size_t)cb * SEG;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = wave + 4 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + piece * 256),
+                                             (__attribute__((address_space(3))) void*)(sB + buf * SEG + piece * 256), 16, 0, 0);
+        }
+    };
+    auto load_item = [&](const Tile& t, int e, int cb) {
+        const char* hb = reinterpret_cast<const char*>(p.src0) + ((((long)(t.n * H + t.y0) * W + t.x0) - (W + 1)) * CIN + cb * 16) * 4;
+        if (e) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const unsigned bad = (eflags >> (4 * k)) & (unsigned)e;
+                const unsigned off = s_off[k] + (bad ? safe_off - s_off[k] : 0u);
+                ra[k] = *reinterpret_cast<const f32x4*>(hb + off);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) ra[k] = *reinterpret_cast<const f32x4*>(hb + s_off[k]);
+        }
+    };
+    int n_coef = -1;
+    auto coefficients = [&](int n) {              // wave-uniform and rare: the sample changes (first item; a range spans few samples)
+        __syncthreads();                          // nobody still reads the old table
+        for (int e = tid; e < CIN; e += 256) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.aff0 + (size_t)n * CIN + e);      // (mean, A, B, -)
+            sC[(e >> 4) * 32 + (e & 15)] = a[1];
+            sC[(e >> 4) * 32 + 16 + (e & 15)] = a[2];
+        }
+        __syncthreads();
+    };
+    auto write_item = [&](const Tile& t, int e, int cb, int buf) {
+        float* img = sA + buf * IMG;
+        if (AFF && t.n != n_coef) { coefficients(t.n); n_coef = t.n; }
+        f32x4 kA = {0.f, 0.f, 0.f, 0.f}, kB = kA;
+        if (AFF) {
+            kA = *reinterpret_cast<const f32x4*>(sC + cb * 32 + part * 4);
+            kB = *reinterpret_cast<const f32x4*>(sC + cb * 32 + 16 + part * 4);
+        }
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (e) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const f32x4 v = AFF ? fma4(ra[k], kA, kB) : ra[k];
+                const bool bad = ((eflags >> (4 * k)) & (unsigned)e) != 0;
+                if (k < NCH - 1 || l_off[NCH - 1] >= 0) *reinterpret_cast<f32x4*>(img + l_off[k]) = bad ? z : v;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (k < NCH - 1 || l_off[NCH - 1] >= 0) *reinterpret_cast<f32x4*>(img + l_off[k]) = AFF ? fma4(ra[k], kA, kB) : ra[k];
+        }
+    };
+
+    const int wty = ((i16 >> 3) & 1) * 2 + ((i16 >> 1) & 1), wtx = ((i16 >> 2) & 1) * 2 + (i16 & 1);
+    const int qy = wave >> 1, qx = wave & 1;
+    const int pbase = (qy * 8 + 2 * wty) * RS + (qx * 8 + 2 * wtx) * 16 + kq * 4;
+    const int bbase = (kq * 16 + i16) * 4;
+    const int co4 = g * 16 + kq * 4;
+    const unsigned out_off = (unsigned)((((qy * 8 + 2 * wty) * W + qx * 8 + 2 * wtx) * COUT + co4) * 4);
+    if (tid < 16) {      // the group's per-channel epilogue constants: read from LDS in the epilogue (one per tile), not held in registers
+        sE[tid] = EPI == EPI_SYNTH ? p.nscale[g * 16 + tid] : 0.f;
+        sE[16 + tid] = EPI == EPI_SYNTH ? p.nbias[g * 16 + tid] : 0.f;
+        sE[32 + tid] = EPI == EPI_DEC ? p.bn_s[g * 16 + tid] : 0.f;
+        sE[48 + tid] = EPI == EPI_DEC ? p.bn_beta[g * 16 + tid] : 0.f;
+    }
+    const unsigned nz_off = (unsigned)((((qy * 8 + 2 * wty) * W + qx * 8 + 2 * wtx)) * 4);
+    f32x2 nz[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const int s2 = stat_s2(H * W);
+    const bool odd = (lane & 1) != 0;
+    unsigned long long dI1[4] = {0ull, 0ull, 0ull, 0ull}, dI2[4] = {0ull, 0ull, 0ull, 0ull};
+    auto flush_stats = [&](int n) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned long long I1 = dI1[c], I2 = dI2[c];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { I1 += shfl_xor_u64(I1, m); I2 += shfl_xor_u64(I2, m); }
+            if (i16 == 0) {
+                StatPart* a = p.partials + ((size_t)n * p.prow + (blockIdx.x & (kDirectRows - 1))) * COUT + co4 + c;
+                atomicAdd(&a->s1, I1);
+                atomicAdd(&a->s2, I2);
+            }
+            dI1[c] = dI2[c] = 0ull;
+        }
+    };
+    const f32x2 k02 = {0.2f, 0.2f};
+    auto epilogue_loads = [&](const Tile& t) {
+        if (EPI == EPI_SYNTH) {
+            const char* nb = reinterpret_cast<const char*>(p.noise) + ((long)(t.n * H + t.y0) * W + t.x0) * 4;
+            nz[0] = *reinterpret_cast<const f32x2*>(nb + nz_off);
+            nz[1] = *reinterpret_cast<const f32x2*>(nb + (long)W * 4 + nz_off);
+        }
+    };
+
+    f32x4 acc[16];
+    auto multiply = [&](auto first_tag, int buf) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const float* a_img = sA + buf * IMG + pbase;
+        const float* b_img = sB + buf * SEG + bbase;
         f32x4 V[16];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -199,7 +513,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_c16(ConvParams p) {
             V[i * 4 + 3] = sub4(t1, t3);
             valu_settle(V[i * 4 + 0], V[i * 4 + 1], V[i * 4 + 2], V[i * 4 + 3]);
         }
-        // sixteen chains, k ascending (channel 4 kq + cg at k slot kq of MFMA cg); weights = A operand, patch = B operand
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
@@ -211,13 +524,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_c16(ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int f = fb * 4 + j;
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][cg], V[f][cg], cg == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[f], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][cg], V[f][cg], FIRST && cg == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[f], 0, 0, 0);
                 }
         }
         __builtin_amdgcn_s_setprio(0);
     };
     auto epilogue = [&](const Tile& t) {
-        // output transform Y = A^T M A: rows s0 = (M0 + M1) + M2, s1 = (M1 - M2) - M3, then the same along the columns
         mfma_settle(acc);
         f32x4 s0[4], s1[4];
 #pragma unroll
@@ -228,42 +540,78 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_c16(ConvParams p) {
         f32x4 y[2][2];
         y[0][0] = add4(add4(s0[0], s0[1]), s0[2]); y[0][1] = sub4(sub4(s0[1], s0[2]), s0[3]);
         y[1][0] = add4(add4(s1[0], s1[1]), s1[2]); y[1][1] = sub4(sub4(s1[1], s1[2]), s1[3]);
-        char* ob = reinterpret_cast<char*>(p.out) + ((long)(t.n * H + t.y0) * W + t.x0) * 64;
+        char* ob = reinterpret_cast<char*>(p.out) + ((long)(t.n * H + t.y0) * W + t.x0) * COUT * 4;
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(sE + kq * 4), e1 = *reinterpret_cast<const f32x4*>(sE + 16 + kq * 4);
+        const f32x4 e2 = *reinterpret_cast<const f32x4*>(sE + 32 + kq * 4), e3 = *reinterpret_cast<const f32x4*>(sE + 48 + kq * 4);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x4 v = y[i][j];
-                if (EPI == EPI_DEC) {
-                    v = lrelu4(fma4(v, e2, e3), k02);
-                    if (RES) v = add4(rr, v);
+                if (EPI == EPI_DEC) v = lrelu4(fma4(v, e2, e3), k02);
+                if (EPI == EPI_SYNTH) {
+                    const f32x2 tlo = j == 0 ? pk_mul2_lo(e0.xy, nz[i]) : pk_mul2_hi(e0.xy, nz[i]);
+                    const f32x2 thi = j == 0 ? pk_mul2_lo(e0.zw, nz[i]) : pk_mul2_hi(e0.zw, nz[i]);
+                    v = lrelu4(add4(add4(v, f32x4{tlo.x, tlo.y, thi.x, thi.y}), e1), k02);
+                    y[i][j] = v;
                 }
-                *reinterpret_cast<f32x4*>(ob + (long)i * W * 64 + out_off + j * 64) = v;
+                *reinterpret_cast<f32x4*>(ob + ((long)i * W + j) * COUT * 4 + out_off) = v;
             }
+        if (EPI == EPI_SYNTH) {      // statistics: see conv3x3_wino_lean
+            f32x4 ps[2], pq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ps[i] = add4(y[i][0], y[i][1]);
+                const f32x2 a0 = pk_mul2(y[i][0].xy, y[i][0].xy), a1 = pk_mul2(y[i][0].zw, y[i][0].zw);
+                const f32x2 b0 = pk_mul2(y[i][1].xy, y[i][1].xy), b1 = pk_mul2(y[i][1].zw, y[i][1].zw);
+                pq[i] = add4(f32x4{a0.x, a0.y, a1.x, a1.y}, f32x4{b0.x, b0.y, b1.x, b1.y});
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float keep_s = odd ? ps[1][c] : ps[0][c], send_s = odd ? ps[0][c] : ps[1][c];
+                const float keep_q = odd ? pq[1][c] : pq[0][c], send_q = odd ? pq[0][c] : pq[1][c];
+                dI1[c] += to_fixed(keep_s + dpp_quad<0xB1>(send_s), kStatScale1);
+                dI2[c] += to_fixed_sq(keep_q + dpp_quad<0xB1>(send_q), s2);
+            }
+        }
     };
 
-    // ---- pipeline: item `it` is multiplied out of LDS buffer it & 1, item it+1 sits in ra, item it+2 is being loaded
     Tile tc, tr;
     {
         const int tx = w_begin % p.tiles_x, r = w_begin / p.tiles_x;
         tc.x0 = tx * 16; tc.y0 = (r % p.tiles_y) * 16; tc.n = r / p.tiles_y;
     }
-    int ec = edge_code(tc), er;
-    load_item(tc, ec);
-    write_item(tc, ec, 0);
+    int ec = edge_code(tc), er, cbc = 0, cbr = 0;
+    auto next_item = [&](Tile& t, int& e, int& cb) {
+        if (++cb == nblk) { cb = 0; advance(t); e = edge_code(t); }
+    };
+    dma_weights(0, 0);
+    load_item(tc, ec, 0);
+    write_item(tc, ec, 0, 0);
     tr = tc; er = ec;
-    if (items > 1) { advance(tr); er = edge_code(tr); load_item(tr, er); }
+    if (items > 1) { next_item(tr, er, cbr); load_item(tr, er, cbr); }
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the four DMA pieces are older than the (at most six) loads of the second item
     __syncthreads();
     for (int it = 0; it < items; ++it) {
         const bool has_next = it + 1 < items;
-        if (has_next) write_item(tr, er, (it + 1) & 1);
-        epilogue_loads(tc);
-        Tile t2 = tr; int e2c = er;
-        if (it + 2 < items) { advance(t2); e2c = edge_code(t2); load_item(t2, e2c); }
-        multiply(it & 1);
-        epilogue(tc);
+        if (has_next) {
+            dma_weights(cbr, (it + 1) & 1);      // the panel buffer item it - 1 used: every wave is past that item's closing barrier
+            write_item(tr, er, cbr, (it + 1) & 1);
+        }
+        if (cbc == nblk - 1) epilogue_loads(tc);
+        Tile t2 = tr; int e2c = er, cb2 = cbr;
+        if (it + 2 < items) { next_item(t2, e2c, cb2); load_item(t2, e2c, cb2); }
+        if (cbc == 0) multiply(std::true_type{}, it & 1);
+        else multiply(std::false_type{}, it & 1);
+        if (cbc == nblk - 1) {
+            epilogue(tc);
+            if (EPI == EPI_SYNTH && (!has_next || tr.n != tc.n)) flush_stats(tc.n);
+        }
+        // this wave's DMA pieces have landed before anybody passes the barrier: they are older than the six loads of item it + 2 (in-order
+        // completion), so at most six outstanding operations means the pieces are in LDS; the younger loads stay in flight
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __syncthreads();
-        tc = tr; ec = er; tr = t2; er = e2c;
+        tc = tr; ec = er; cbc = cbr; tr = t2; er = e2c; cbr = cb2;
     }
 }
 
@@ -271,11 +619,11 @@ constexpr int kMaxDev = 64;
 struct LeanState { bool attr_done = false; int cus = 0; };
 static std::mutex g_mu;
 
-template <int EPI, bool AFF, bool RES>
+template <int EPI, bool AFF, bool RES, int NB, int GW, bool DB = true>
 hipError_t launch_t(const ConvParams& p, int n, hipStream_t s) {
     static LeanState st[kMaxDev];
-    auto kern = conv3x3_wino_c16<EPI, AFF, RES>;
-    const size_t lds = sizeof(float) * (2 * IMG + SEG);
+    auto kern = conv3x3_wino_lean<EPI, AFF, RES, NB, GW, DB>;
+    const size_t lds = sizeof(float) * ((DB ? 2 : 1) * IMG + GW * NB * SEG);
     if (p.device < 0 || p.device >= kMaxDev) return hipErrorInvalidDevice;
     int cus;
     {
@@ -295,35 +643,114 @@ hipError_t launch_t(const ConvParams& p, int n, hipStream_t s) {
     q.tiles_y = p.H / 16;
     q.groups = 1;
     q.total_tiles = q.tiles_x * q.tiles_y * n;
-    const int gx = std::min(q.total_tiles, cus * 2);      // persistent: two workgroups per CU (58 KB of LDS each)
-    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, s, q);
+    if (EPI == EPI_SYNTH) {      // direct statistics: the sums go to kDirectRows zeroed rows per sample (finalize_kernel clears what it read)
+        q.stats_direct = 1;
+        q.prow = kDirectRows;
+        if (p.stat_rows_host) *p.stat_rows_host = q.prow;
+    }
+    // persistent workgroups: two 4-wave workgroups per CU (58 KB of LDS each) or one 8-wave workgroup (106 KB), each a contiguous tile range
+    const int gx = std::min(q.total_tiles, cus * (GW == 1 ? (DB ? 2 : 3) : 1));
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(256 * GW), lds, s, q);
+    return hipGetLastError();
+}
+
+// GSA_WINO_LEAN_SB=1: the single-buffered three-workgroups-per-CU form for the 16 -> 16 decoder layers (A/B; same bits)
+bool single_buffered() {
+    static const bool on = getenv("GSA_WINO_LEAN_SB") && atoi(getenv("GSA_WINO_LEAN_SB")) != 0;
+    return on;
+}
+
+template <int NB, int GW>
+hipError_t launch_shape(const ConvParams& p, int epi, int n, hipStream_t s) {
+    if constexpr (NB == 1 && GW == 1) {
+        if (epi == EPI_DEC && single_buffered()) {
+            if (p.resid) return p.aff0 ? launch_t<EPI_DEC, true, true, 1, 1, false>(p, n, s) : launch_t<EPI_DEC, false, true, 1, 1, false>(p, n, s);
+            return p.aff0 ? launch_t<EPI_DEC, true, false, 1, 1, false>(p, n, s) : launch_t<EPI_DEC, false, false, 1, 1, false>(p, n, s);
+        }
+    }
+    if (epi == EPI_DEC) {
+        if (p.resid) return p.aff0 ? launch_t<EPI_DEC, true, true, NB, GW>(p, n, s) : launch_t<EPI_DEC, false, true, NB, GW>(p, n, s);
+        return p.aff0 ? launch_t<EPI_DEC, true, false, NB, GW>(p, n, s) : launch_t<EPI_DEC, false, false, NB, GW>(p, n, s);
+    }
+    if (epi == EPI_SYNTH) return p.aff0 ? launch_t<EPI_SYNTH, true, false, NB, GW>(p, n, s) : launch_t<EPI_SYNTH, false, false, NB, GW>(p, n, s);
+    return hipErrorInvalidValue;
+}
+
+template <int EPI, bool AFF>
+hipError_t launch_stream_t(const ConvParams& p, int n, hipStream_t s) {
+    static LeanState st[kMaxDev];
+    auto kern = conv3x3_wino_stream<EPI, AFF>;
+    const int nblk = p.C0 / 16;
+    const size_t lds = sizeof(float) * (2 * IMG + 2 * SEG + 64 + nblk * 32);
+    if (p.device < 0 || p.device >= kMaxDev) return hipErrorInvalidDevice;
+    int cus;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        LeanState& d = st[p.device];
+        if (!d.attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            if (hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, p.device) != hipSuccess) d.cus = 256;
+            d.attr_done = true;
+        }
+        cus = d.cus;
+    }
+    ConvParams q = p;
+    q.wpk = p.wino;
+    q.tiles_x = p.W / 16;
+    q.tiles_y = p.H / 16;
+    q.groups = p.Cout / 16;
+    q.total_tiles = q.tiles_x * q.tiles_y * n;         // per output-channel group
+    if (EPI == EPI_SYNTH) {
+        q.stats_direct = 1;
+        q.prow = kDirectRows;
+        if (p.stat_rows_host) *p.stat_rows_host = q.prow;
+    }
+    // persistent workgroups, two per CU, each inside its channel group; workgroup (x, g) has the linear index x + g * gx: with gx a
+    // multiple of 8 the groups of a tile range meet in one XCD's L2 (conv3x3_wino's launch shape)
+    const int slots = std::max(1, cus * 2 / q.groups);
+    const int gx = std::min(q.total_tiles, slots);
+    hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256), lds, s, q);
     return hipGetLastError();
 }
 
 }  // namespace lean
 using namespace lean;
 
-// the layers this file takes: Winograd form (conv_uses_wino), 16 -> 16 channels, decoder epilogue, residual absent or one half-resolution tensor
+// the layers this file takes: Winograd form (conv_uses_wino), 16 -> 16 or 32 -> 32 channels, output >= 32 px, synthesis epilogue with direct
+// statistics or decoder epilogue with the residual absent or one half-resolution tensor.  GSA_WINO_LEAN=0 keeps conv3x3_wino (same bits).
 bool wino_lean_applies(const ConvParams& p, int epi) {
-    static const bool enabled = !(getenv("GSA_WINO_LEAN") && atoi(getenv("GSA_WINO_LEAN")) == 0);
-    if (!enabled || p.C0 != 16 || p.Cout != 16 || p.H < 32 || p.H != p.W || p.H % 16) return false;
+    static const int enabled = getenv("GSA_WINO_LEAN") ? atoi(getenv("GSA_WINO_LEAN")) : 7;      // bit 0: 16 -> 16, bit 1: 32 -> 32
+    if (p.H != p.W || p.H % 16) return false;
+    if ((enabled & 4) && p.C0 >= 64 && p.C0 <= 512 && p.resid == nullptr && p.H >= 16)      // bit 2: the streamed-weight layers
+        return epi == EPI_SYNTH ? (p.partials != nullptr && p.noise != nullptr && p.fin_aff == nullptr) : epi == EPI_DEC;
+    const bool shape = (p.C0 == 16 && p.Cout == 16 && (enabled & 1)) || (p.C0 == 32 && p.Cout == 32 && (enabled & 2));
+    if (!shape || p.H < 32) return false;
+    if (epi == EPI_SYNTH) return p.partials != nullptr && p.noise != nullptr && p.fin_aff == nullptr && p.resid == nullptr;
     if (epi != EPI_DEC) return false;
     if (p.resid != nullptr && (p.resid_up != 1 || p.resid1 != nullptr)) return false;
     return true;
 }
 
 const char* wino_lean_name(const ConvParams& p, int epi) {
-    static thread_local char buf[96];
-    snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_c16<%d, %s, %s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false",
-             p.resid ? "true" : "false");
+    static thread_local char buf[112];
+    if (p.C0 >= 64) {
+        snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_stream<%d, %s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false");
+        return buf;
+    }
+    snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_lean<%d, %s, %s, %d, %d>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false",
+             p.resid ? "true" : "false", p.C0 / 16, p.Cout / 16);
     return buf;
 }
 
 hipError_t launch_wino_lean(const ConvParams& p, int epi, int n, hipStream_t s) {
-    if (epi == EPI_DEC) {
-        if (p.resid) return p.aff0 ? launch_t<EPI_DEC, true, true>(p, n, s) : launch_t<EPI_DEC, false, true>(p, n, s);
-        return p.aff0 ? launch_t<EPI_DEC, true, false>(p, n, s) : launch_t<EPI_DEC, false, false>(p, n, s);
+    if (p.C0 >= 64) {
+        if (epi == EPI_SYNTH) return p.aff0 ? launch_stream_t<EPI_SYNTH, true>(p, n, s) : launch_stream_t<EPI_SYNTH, false>(p, n, s);
+        if (epi == EPI_DEC) return p.aff0 ? launch_stream_t<EPI_DEC, true>(p, n, s) : launch_stream_t<EPI_DEC, false>(p, n, s);
+        return hipErrorInvalidValue;
     }
+    if (p.C0 == 16 && p.Cout == 16) return launch_shape<1, 1>(p, epi, n, s);
+    if (p.C0 == 32 && p.Cout == 32) return launch_shape<2, 2>(p, epi, n, s);
     return hipErrorInvalidValue;
 }
 
