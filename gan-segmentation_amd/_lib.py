@@ -12,6 +12,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIBRARY = os.path.join(_HERE, "csrc", "libgsa_hip.so")
+EXPERIMENTS_LIBRARY = os.path.join(_HERE, "csrc", "libgsa_hip_exp.so")      # `make experiments`: + the measured-slower kernels behind their switches
+if os.environ.get("GSA_HIP_LIBRARY"):      # tests / A-B runs: another build of the same library (a file name inside csrc/, or a path)
+    _alt = os.environ["GSA_HIP_LIBRARY"]
+    HIP_LIBRARY = _alt if os.path.isabs(_alt) else os.path.join(_HERE, "csrc", _alt)
 
 # every symbol include/gsa.h declares
 API_SYMBOLS = (

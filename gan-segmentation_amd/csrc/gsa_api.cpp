@@ -526,7 +526,14 @@ extern "C" {
 #define GSA_STR2(x) #x
 #define GSA_STR(x) GSA_STR2(x)
 const char* gsa_version(void) {
-    return "gsa-hip 0.3 (gfx950, v_mfma_f32_16x16x4_f32 implicit-GEMM convs; built with hipcc = clang " __clang_version__
+#ifndef GSA_EXPERIMENTS
+#define GSA_EXPERIMENTS 0
+#endif
+    return "gsa-hip 0.5"
+#if GSA_EXPERIMENTS
+           "+experiments"
+#endif
+           " (gfx950, v_mfma_f32_16x16x4_f32 implicit-GEMM convs; built with hipcc = clang " __clang_version__
            ", HIP " GSA_STR(HIP_VERSION_MAJOR) "." GSA_STR(HIP_VERSION_MINOR) "." GSA_STR(HIP_VERSION_PATCH) ")";
 }
 

@@ -92,6 +92,10 @@ bool conv_uses_wino(const ConvParams& p, int epi, bool shortcut);   // true: Win
 bool wino_lean_applies(const ConvParams& p, int epi);
 const char* wino_lean_name(const ConvParams& p, int epi);
 hipError_t launch_wino_lean(const ConvParams& p, int epi, int n, hipStream_t s);
+// gsa_sub_lean.hip (round 5): subpixel_res<..., WINO> (fp32) in a leaner instruction stream -- speed only, same bits (GSA_SUB_LEAN=0: subpixel_res)
+bool subpixel_lean_applies(const ConvParams& p, int nt, int epi, bool sc, int kb, bool wst);
+const char* subpixel_lean_name(const ConvParams& p, int nt, int epi, bool sc, int kb, bool wst);
+hipError_t launch_subpixel_lean(const ConvParams& q, int nt, int epi, bool sc, int kb, bool wst, dim3 grid, hipStream_t s);
 hipError_t launch_subpixel(const ConvParams& p, int epi, bool shortcut, int n, hipStream_t s);   // deconv4x4s2 / sub-pixel up+conv
 bool subpixel_uses_wino(const ConvParams& p);                      // true: Winograd F(2x2,2x2) form (static rule: fp32 mode): 9 products per 2x2 class outputs instead of 163x3
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s);

@@ -49,6 +49,10 @@
 #ifndef GSA_DB_SMALL
 #define GSA_DB_SMALL 1
 #endif
+#ifndef GSA_EXPERIMENTS
+#define GSA_EXPERIMENTS 0      // 1 (`make experiments` -> libgsa_hip_exp.so): also build the measured-slower kernels of round 4 behind their switches
+#endif
+
 
 namespace gsa {
 
@@ -1482,6 +1486,11 @@ __global__ __launch_bounds__(256 * GW * TW, NT == 1 ? 2 / TW : 1) void conv3x3_w
     TFLUSH(12, (unsigned long long)total_items); TFLUSH(15, 1ull);
 }
 
+#if GSA_EXPERIMENTS      // the measured-slower kernels of round 4 (conv3x3_wino_dma, conv3x3_wino43): `make experiments` builds them into libgsa_hip_exp.so
+// Every barrier of these two kernels publishes LDS-DMA data: the issuing wave waits for its own DMA explicitly (vmcnt) before the
+// barrier -- gfx950's s_barrier does not wait for outstanding vector-memory operations, and relying on the compiler's conservative
+// placement of its own waits tied the kernels to one hipcc.
+#define GSA_DMA_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 // ------------------------------------------------------------------------------------------
 // conv3x3_wino with ALL staging by LDS-DMA (round 4) -- the streamed-weight layers (>= 64 input channels, one output-channel group
 // per workgroup): same workgroup geometry, same LDS image addresses, same MFMAs, same epilogue, same bits as conv3x3_wino<EPI, 1,
@@ -1720,7 +1729,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_dma(ConvParams p) {
                 if ((unsigned)(tc.x0 + pcol + r - 1) < (unsigned)p.W) colin |= 1u << r;
             }
         }
-        __syncthreads();                         // item `it` has landed; every wave has left the buffer the next DMA overwrites
+        GSA_DMA_SYNC();                         // item `it` has landed; every wave has left the buffer the next DMA overwrites
         TICK(k1);
         Tile tn = tc; int cbn = cb + 1; unsigned mask_n = mask_c;
         if (cbn == nblk) { cbn = 0; if (has_next) { tn = advance(tc); mask_n = tile_mask(tn); } }
@@ -2125,7 +2134,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43(ConvParams p) {
             const f32x4 a0 = ap[0], a1 = ap[1];
             cA = f32x2{a0[1], a1[1]}; cB = f32x2{a0[2], a1[2]};
         }
-        __syncthreads();                         // item `it` has landed (the compiler waits for this wave's DMA before the barrier); buffer (it+1) & 1 is free
+        GSA_DMA_SYNC();                         // item `it` has landed (the compiler waits for this wave's DMA before the barrier); buffer (it+1) & 1 is free
         TICK(k1);
         int wi2 = wi, cb2 = cb + 1;
         WT tn = tc;
@@ -2153,6 +2162,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43(ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+#endif      // GSA_EXPERIMENTS
+
 // Winograd F(2x2, 2x2) form of the stride-2 parity-class convolutions (round 3; canonical arithmetic:
 // oracle/c/gsa_oracle.c deconv4x4s2_wino).  A parity class (py, px) of the 4x4 stride-2 transposed
 // convolution is a 2x2-tap stride-1 convolution; per 2x2 class outputs the Winograd form needs 9 products instead of 16:
@@ -3592,7 +3603,7 @@ __global__ __launch_bounds__(256) void import_nhwc_kernel(const float* in, float
 // Final conv3x3 (in_c -> NCLS classes) + bias + argmax (first maximum wins).  NCLS is tiny
 // (2 in the reference), so the contraction runs on the vector ALU: one thread per pixel,
 // input tile staged in LDS, weights through uniform (scalar) loads.
-template <int NCLS, bool BF>
+template <int NCLS, bool BF, bool PK = false>
 __global__ __launch_bounds__(256) void final_conv_kernel(const float* src0, int C0, const float* src1, int C1,
                                                          const float* wpk, const float* bias, float* logits,
                                                          uint8_t* mask, int H, int W, int tiles_x) {
@@ -3656,9 +3667,22 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* src0, int 
                 const float4 a = a4[k];
                 const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (NCLS % 2 == 0 && PK) {
+                        // round 5: the chains of two classes as ONE v_pk_fma_f32 (the value broadcast, the class pair's weights as a scalar
+                        // register pair): the same fmaf per class in the same order, half the vector-ALU instructions of a kernel that was
+                        // half vector-ALU bound (576 fma per pixel at 1024^2 beside 1.1 GB of reads)
 #pragma unroll
-                    for (int o = 0; o < NCLS; ++o) acc[o] = fmaf(av[j], wb[(tap * 16 + k * 4 + j) * NCLS + o], acc[o]);
+                        for (int o = 0; o < NCLS; o += 2) {
+                            const f32x2 w2 = {wb[(tap * 16 + k * 4 + j) * NCLS + o], wb[(tap * 16 + k * 4 + j) * NCLS + o + 1]};
+                            const f32x2 r = __builtin_elementwise_fma(f32x2{av[j], av[j]}, w2, f32x2{acc[o], acc[o + 1]});
+                            acc[o] = r.x; acc[o + 1] = r.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int o = 0; o < NCLS; ++o) acc[o] = fmaf(av[j], wb[(tap * 16 + k * 4 + j) * NCLS + o], acc[o]);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -4049,6 +4073,7 @@ static hipError_t launch_wino_t(const ConvParams& p, int n, hipStream_t s) {
 // OPT-IN: GSA_WINO43=1 selects it -- a different canonical arithmetic (the oracle has GSAO_WINO43=1), bit-exact against that oracle
 // and within the 1e-3 tolerance, but measured 15-20 % SLOWER than F(2x2,3x3) on these layers: the
 // product keeps F(2x2,3x3).
+#if GSA_EXPERIMENTS
 bool wino43_enabled() {
     static const bool enabled = getenv("GSA_WINO43") && atoi(getenv("GSA_WINO43")) != 0;
     return enabled;
@@ -4095,6 +4120,11 @@ static hipError_t launch_wino43(const ConvParams& p, int epi, int n, hipStream_t
     return launch_wino43_t<EPI_DEC>(p, n, s);
 }
 
+#else
+bool wino43_enabled() { return false; }
+bool conv_uses_wino43(const ConvParams&, int, bool) { return false; }
+#endif
+
 // staging form of the Winograd kernel: 16-byte chunks from 64 input channels on, whole pixels below (measured; speed only)
 static bool wino_chunk(const ConvParams& p) {
     static const int forced = getenv("GSA_WINO_CHUNK") ? atoi(getenv("GSA_WINO_CHUNK")) : -1;
@@ -4112,6 +4142,7 @@ static int wino_gw(const ConvParams& p) {
     return (forced >= 2 || p.C0 <= 32) ? 2 : 1;
 }
 
+#if GSA_EXPERIMENTS
 // conv3x3_wino_dma: the streamed-weight layers (>= 64 input channels) with every operand staged by LDS-DMA.  Speed only -- the same
 // arithmetic as conv3x3_wino, same bits -- and measured 8-10 % SLOWER (g.64.conv_2 0.250 vs 0.227 ms: ~260 cycles per DMA instruction
 // with eight waves per CU, and every wave waits at the barrier for the slowest wave's DMA): opt-in, GSA_WINO_DMA=1, for A/B runs.
@@ -4162,13 +4193,20 @@ static int wino_tw(const ConvParams& p) {
     return (forced == 2 && p.Cout == 16 && p.C0 <= 32 && p.W % 32 == 0 && wino_nt(p) == 1 && !wino_chunk(p)) ? 2 : 1;
 }
 
+#else
+static bool wino_dma(const ConvParams&, int) { return false; }
+static int wino_tw(const ConvParams&) { return 1; }
+#endif
+
 static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s) {
-    if (wino_lean_applies(p, epi)) return launch_wino_lean(p, epi, n, s);
+#if GSA_EXPERIMENTS      // an explicitly selected experiment wins over the lean kernels
     if (wino_dma(p, epi) && wino_nt(p) == 1) return launch_wino_dma(p, epi, n, s);
     if (wino_tw(p) == 2) {
         if (epi == EPI_SYNTH) return p.aff0 ? launch_wino_t<EPI_SYNTH, 1, false, true, 1, 2>(p, n, s) : launch_wino_t<EPI_SYNTH, 1, false, false, 1, 2>(p, n, s);
         return p.aff0 ? launch_wino_t<EPI_DEC, 1, false, true, 1, 2>(p, n, s) : launch_wino_t<EPI_DEC, 1, false, false, 1, 2>(p, n, s);
     }
+#endif
+    if (wino_lean_applies(p, epi)) return launch_wino_lean(p, epi, n, s);
     const int nt = wino_nt(p);
     const int gw = wino_gw(p);
     const bool ch = wino_chunk(p);
@@ -4192,7 +4230,7 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_wino43<%d>(gsa::ConvParams)", epi);
         return buf;
     }
-    if (conv_uses_wino(p, epi, sc) && wino_lean_applies(p, epi)) return wino_lean_name(p, epi);
+    if (conv_uses_wino(p, epi, sc) && !(wino_dma(p, epi) && wino_nt(p) == 1) && wino_tw(p) != 2 && wino_lean_applies(p, epi)) return wino_lean_name(p, epi);
     if (conv_uses_wino(p, epi, sc) && wino_dma(p, epi) && wino_nt(p) == 1) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_wino_dma<%d, %s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false");
         return buf;
@@ -4217,7 +4255,9 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
 
 hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStream_t s) {
     if (p.H != p.W || (p.H & (p.H - 1)) || p.H < 4 || p.Cout % 16 || p.C0 % 16 || p.C1 % 16) return hipErrorInvalidValue;
+#if GSA_EXPERIMENTS
     if (conv_uses_wino43(p, epi, sc)) return launch_wino43(p, epi, n, s);
+#endif
     if (conv_uses_wino(p, epi, sc)) return launch_wino(p, epi, n, s);
     if (conv_uses_ksplit(p, sc)) return launch_ksplit(p, epi, n, s);
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
@@ -4280,6 +4320,7 @@ static hipError_t launch_subpixel_res_k(const ConvParams& p, int n, size_t lds, 
     q.groups = 1;
     q.total_tiles = q.tiles_x * q.tiles_y * n;
     const int grid = std::min(num_cus, (q.total_tiles + 1) / 2);
+    if (WINO && !BF && subpixel_lean_applies(q, NT, EPI, SC, KB, false)) return launch_subpixel_lean(q, NT, EPI, SC, KB, false, dim3(grid), s);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, q);
     return hipGetLastError();
 }
@@ -4300,6 +4341,7 @@ static hipError_t launch_subpixel_wst_t(const ConvParams& p, int n, size_t lds, 
     q.tiles_y = p.H / 16;
     q.groups = p.Cout / (16 * NT);
     q.total_tiles = q.tiles_x * q.tiles_y * n;       // per channel group
+    if (WINO && !BF && subpixel_lean_applies(q, NT, EPI, SC, 1, true)) return launch_subpixel_lean(q, NT, EPI, SC, 1, true, dim3(wgs_per_g, q.groups), s);
     hipLaunchKernelGGL(kern, dim3(wgs_per_g, q.groups), dim3(512), lds, s, q);
     return hipGetLastError();
 }
@@ -4371,6 +4413,10 @@ const char* subpixel_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     const int ct = subpixel_cout_tile(p.H, p.W, p.Cout, n, sub_wino(p));
     const bool res = subpixel_res_lds(p, ct, sc, n) != 0;
     int wgs_per_g = 0;
+    if (res && sub_wino(p) && !p.bf16 && subpixel_lean_applies(p, ct / 16, epi, sc, subpixel_res_kb(p), false))
+        return subpixel_lean_name(p, ct / 16, epi, sc, subpixel_res_kb(p), false);
+    if (!res && sub_wino(p) && !p.bf16 && subpixel_wst_lds(p, ct, sc, n, &wgs_per_g) && subpixel_lean_applies(p, ct / 16, epi, sc, 1, true))
+        return subpixel_lean_name(p, ct / 16, epi, sc, 1, true);
     if (res)
         snprintf(buf, sizeof buf, "void gsa::subpixel_res<%d, %d, %s, %s, %d, false, %s>(gsa::ConvParams)", ct / 16, epi, sc ? "true" : "false",
                  p.bf16 ? "true" : "false", subpixel_res_kb(p), wn);
@@ -4618,12 +4664,20 @@ hipError_t launch_import_nhwc(const float* in, float* out, int n, int H, int W, 
     return hipGetLastError();
 }
 
+// class pairs as packed fma in the fp32 final conv (speed only, same bits; GSA_FINAL_PK=0: the scalar chains)
+static bool final_pk() {
+    static const bool on = !(getenv("GSA_FINAL_PK") && atoi(getenv("GSA_FINAL_PK")) == 0);
+    return on;
+}
+
 template <int NCLS>
 static hipError_t launch_final_t(const float* src0, int C0, const float* src1, int C1, const float* wpk, const float* bias,
                                  float* logits, uint8_t* mask, int n, int H, int W, int bf16, hipStream_t s) {
     const size_t lds = sizeof(float) * 18 * 384;
     if (bf16) hipLaunchKernelGGL((final_conv_kernel<NCLS, true>), dim3((H / 16) * (W / 16), n), dim3(256), lds, s, src0, C0, src1, C1, wpk,
                                  bias, logits, mask, H, W, W / 16);
+    else if (NCLS % 2 == 0 && final_pk()) hipLaunchKernelGGL((final_conv_kernel<NCLS, false, true>), dim3((H / 16) * (W / 16), n), dim3(256), lds, s, src0, C0, src1, C1, wpk,
+                            bias, logits, mask, H, W, W / 16);
     else hipLaunchKernelGGL((final_conv_kernel<NCLS, false>), dim3((H / 16) * (W / 16), n), dim3(256), lds, s, src0, C0, src1, C1, wpk,
                             bias, logits, mask, H, W, W / 16);
     return hipGetLastError();

@@ -589,8 +589,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
     load_item(tc, ec, 0);
     write_item(tc, ec, 0, 0);
     tr = tc; er = ec;
-    if (items > 1) { next_item(tr, er, cbr); load_item(tr, er, cbr); }
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the four DMA pieces are older than the (at most six) loads of the second item
+    if (items > 1) {
+        next_item(tr, er, cbr);
+        load_item(tr, er, cbr);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the four DMA pieces are older than the six loads of the second item
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     for (int it = 0; it < items; ++it) {
         const bool has_next = it + 1 < items;
@@ -608,8 +613,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
             if (EPI == EPI_SYNTH && (!has_next || tr.n != tc.n)) flush_stats(tc.n);
         }
         // this wave's DMA pieces have landed before anybody passes the barrier: they are older than the six loads of item it + 2 (in-order
-        // completion), so at most six outstanding operations means the pieces are in LDS; the younger loads stay in flight
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // completion), so at most six outstanding operations means the pieces are in LDS and the younger loads stay in flight; an
+        // iteration that issued no such loads (the last two) waits for everything
+        if (it + 2 < items) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         tc = tr; ec = er; cbc = cbr; tr = t2; er = e2c; cbr = cb2;
     }

@@ -866,9 +866,13 @@ def test_winograd_f4x4_form_is_bit_exact_when_selected(torch_cuda, tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from gan_segmentation_amd import _lib
+    if not os.path.exists(_lib.EXPERIMENTS_LIBRARY):
+        pytest.skip("libgsa_hip_exp.so is not built (make -C gan-segmentation_amd/csrc experiments)")
     script = tmp_path / "w43_worker.py"
     script.write_text(_W43_WORKER.replace("ROOT_DIR", repr(root)))
-    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, GSA_WINO43="1", GSAO_WINO43="1"), capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, GSA_WINO43="1", GSAO_WINO43="1", GSA_HIP_LIBRARY="libgsa_hip_exp.so"),
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "W43_OK" in out.stdout, out.stdout[-800:] + out.stderr[-2500:]
 
 
@@ -886,10 +890,21 @@ print("SWITCH_OK")
 '''
 
 
-@pytest.mark.parametrize("env", [{"GSA_WINO_NT": "2"}, {"GSA_WINO_GM": "0"}, {"GSA_WINO_CHUNK": "1"}, {"GSA_WINO_CHUNK": "0"}, {"GSA_POST_RPT": "1"}, {"GSA_POST_RPT": "8"},
-                                 {"GSA_SIDE_LEVELS": "0"}, {"GSA_MAPFUSE": "0"}, {"GSA_KSPLIT_PS": "1"}, {"GSA_FEWROWS": "0"}, {"GSA_WRES": "0", "GSA_SUBRES": "0", "GSA_STATS_DIRECT": "0"},
-                                 {"GSA_WINO_GW": "1"}, {"GSA_WINO_GW": "2"}, {"GSA_WINO_PERS": "32"}, {"GSA_POST_NG": "4"}, {"GSA_SUBWST": "0"},      # round 3
-                                 {"GSA_WINO_DMA": "1"}, {"GSA_FUSEFIN": "0"}, {"GSA_WINO_TW": "2"}])      # round 4: conv3x3_wino_dma (every operand by LDS-DMA); post pass and finalize as two launches; two tiles per 8-wave workgroup
+_OLD = {"GSA_WINO_LEAN": "0", "GSA_SUB_LEAN": "0", "GSA_POST_PK": "0"}      # the kernels of rounds 1-4 (the fallbacks): their own switches only act there
+_EXP = {"GSA_HIP_LIBRARY": "libgsa_hip_exp.so"}                               # `make experiments`: + the measured-slower kernels of round 4
+
+
+@pytest.mark.parametrize("env", [
+    # round 5: the lean kernels off / partly on, the single-buffered three-workgroups-per-CU form, the packed post pass and final conv
+    _OLD, {"GSA_WINO_LEAN": "1"}, {"GSA_WINO_LEAN": "3"}, {"GSA_SUB_LEAN": "0"}, {"GSA_POST_PK": "0"}, {"GSA_POST_PK": "2"}, {"GSA_FINAL_PK": "0"},
+    {"GSA_WINO_LEAN_SB": "1"},
+    # rounds 2-4, on the fallback kernels they belong to
+    dict(_OLD, GSA_WINO_NT="2"), dict(_OLD, GSA_WINO_GM="0"), dict(_OLD, GSA_WINO_CHUNK="1"), dict(_OLD, GSA_WINO_CHUNK="0"), dict(_OLD, GSA_POST_RPT="1"),
+    dict(_OLD, GSA_POST_RPT="8"), {"GSA_SIDE_LEVELS": "0"}, {"GSA_MAPFUSE": "0"}, {"GSA_KSPLIT_PS": "1"}, {"GSA_FEWROWS": "0"},
+    dict(_OLD, GSA_WRES="0", GSA_SUBRES="0", GSA_STATS_DIRECT="0"), dict(_OLD, GSA_WINO_GW="1"), dict(_OLD, GSA_WINO_GW="2"), dict(_OLD, GSA_WINO_PERS="32"),
+    dict(_OLD, GSA_POST_NG="4"), dict(_OLD, GSA_SUBWST="0"), {"GSA_SUBWST": "0"}, {"GSA_FUSEFIN": "0"},
+    # round 4's measured-slower kernels: in the experiments build only (conv3x3_wino_dma: every operand by LDS-DMA; two tiles per 8-wave workgroup)
+    dict(_EXP, GSA_WINO_DMA="1"), dict(_EXP, GSA_WINO_TW="2")])
 def test_speed_switches_do_not_change_the_bits(torch_cuda, tmp_path, env):
     """The A/B switches of DESIGN.md section 4 that are NOT part of the canonical arithmetic (channel tile of the Winograd
     kernel, group order, rows per thread of the post kernel, stream overlap, resident weights / persistent forms / direct
@@ -898,6 +913,10 @@ def test_speed_switches_do_not_change_the_bits(torch_cuda, tmp_path, env):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if "GSA_HIP_LIBRARY" in env:
+        from gan_segmentation_amd import _lib
+        if not os.path.exists(_lib.EXPERIMENTS_LIBRARY):
+            pytest.skip("libgsa_hip_exp.so is not built (make -C gan-segmentation_amd/csrc experiments)")
     script = tmp_path / "switch_worker.py"
     script.write_text(_SWITCH_WORKER.replace("ROOT_DIR", repr(root)))
     out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
