@@ -101,32 +101,6 @@ struct TilePixel {   // one staged pixel of this thread
 // structs; the element index is the same in both modes, the element size is not.  Arithmetic stays fp32: a consumer widens
 // (exact), applies AdaIN in fp32 and rounds to bf16 (RNE) once more for the MFMA operand; statistics are taken from the fp32
 // values before the producer rounds them for storage.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-
-template <bool BF>
-__device__ __forceinline__ f32x4 act_load4(const float* base, size_t idx) {      // 4 consecutive channels at element idx
-    if constexpr (BF) {
-        const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx);
-        return f32x4{bf16_lo(r[0]), bf16_hi(r[0]), bf16_lo(r[1]), bf16_hi(r[1])};
-    } else {
-        return *reinterpret_cast<const f32x4*>(base + idx);
-    }
-}
-
-template <bool BF>
-__device__ __forceinline__ void act_store4(float* base, size_t idx, const f32x4& v) {
-    if constexpr (BF) {
-        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + idx) =
-            u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2)),
-                  __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2))};
-    } else {
-        *reinterpret_cast<f32x4*>(base + idx) = v;
-    }
-}
-
 // Unconditional loads (padding / idle threads read pixel 0 and discard it): no branch sits
 // between a global load and its use, so the compiler keeps every load of a block in flight.
 // BF: the 16 channels of the block are 32 bytes; they travel as raw bits in v[0], v[1].
@@ -4530,8 +4504,8 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
     q.row_groups = post_row_groups(p);
     dim3 grid(post_blocks(p), n);
     const size_t lds = sizeof(unsigned long long) * 2 * p.C;
-    // the packed-arithmetic form (gsa_post_lean.hip): fp32, four rows per thread, a wave's 64 threads inside one row group
-    if (rpt == 4 && !p.bf16 && post_pk_mode() > 0 && ((p.W / 4) * (p.C / 4)) % 64 == 0)
+    // the packed-arithmetic form (gsa_post_lean.hip): four rows per thread, a wave's 64 threads inside one row group
+    if (rpt == 4 && post_pk_mode() > 0 && ((p.W / 4) * (p.C / 4)) % 64 == 0)
         return launch_post_pk(q, grid, lds + sizeof(float) * 9 * p.C, s);
 #define GSA_POST(BF) \
     if (rpt == 8) hipLaunchKernelGGL((post_rows_kernel<8, BF>), grid, dim3(256), lds, s, q); \

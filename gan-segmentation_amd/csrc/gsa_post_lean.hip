@@ -13,9 +13,11 @@
 namespace gsa {
 namespace lean {
 
-template <bool NT>
+// BF: the source and the output are bf16 tensors (bf16 mode: half the bytes; the arithmetic and the statistics stay fp32, the output is
+// rounded to bf16 (RNE) when it is stored -- post_rows_kernel<4, true>'s rule)
+template <bool NT, bool BF>
 __global__ __launch_bounds__(256, 2) void post_rows_pk(PostParams p) {
-    constexpr int RPT = 4;
+    constexpr int RPT = 4, ES = BF ? 2 : 4;      // bytes per activation element
     extern __shared__ __attribute__((aligned(16))) unsigned long long sstat[];   // [2][C], then the blur taps [9][C] as floats
     float* const sW = reinterpret_cast<float*>(sstat + 2 * p.C);
     const int n = blockIdx.y;
@@ -34,20 +36,20 @@ __global__ __launch_bounds__(256, 2) void post_rows_pk(PostParams p) {
         // the launcher guarantees W4 * C4 % 64 == 0: the 64 threads of a wave share their rows, so every row base is a scalar
         const int y0 = __builtin_amdgcn_readfirstlane((t / W4) * (RPT * NG));
         const int c = cq * 4, x0 = xq * 4;
-        const char* const sb = reinterpret_cast<const char*>(p.src + (size_t)n * p.H * p.W * p.C);      // this sample: wave-uniform
-        char* const ob = reinterpret_cast<char*>(p.out + (size_t)n * p.H * p.W * p.C);
+        const char* const sb = reinterpret_cast<const char*>(p.src) + (size_t)n * p.H * p.W * p.C * ES;      // this sample: wave-uniform
+        char* const ob = reinterpret_cast<char*>(p.out) + (size_t)n * p.H * p.W * p.C * ES;
         const char* const nzb = reinterpret_cast<const char*>(p.noise + (size_t)n * p.H * p.W);
         const volatile f32x4* wtap = reinterpret_cast<const volatile f32x4*>(sW + c);      // tap t of channels c .. c+3 at wtap[t * C4]
         const f32x4 sf = *reinterpret_cast<const f32x4*>(p.nscale + c);
         const f32x4 nb = *reinterpret_cast<const f32x4*>(p.nbias + c);
         const f32x2 k02 = {0.2f, 0.2f};
-        const unsigned rowb = (unsigned)(p.W * p.C * 4);      // bytes per row
+        const unsigned rowb = (unsigned)(p.W * p.C * ES);     // bytes per row
         unsigned xoff[6], xin = 0;                            // byte offset of (x0 - 1 + k, c) inside a row (clamped), inside-the-image bits
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int xx = x0 - 1 + k;
             if (xx >= 0 && xx < p.W) xin |= 1u << k;
-            xoff[k] = (unsigned)(((xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx)) * p.C + c) * 4);
+            xoff[k] = (unsigned)(((xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx)) * p.C + c) * ES);
         }
         auto load_row = [&](f32x4 (&row)[6], int yy) {      // unconditional loads (clamped), padding = zeroed values; yy is wave-uniform
             const bool vy = yy >= 0 && yy < p.H;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void post_rows_pk(PostParams p) {
             const char* rp = sb + (size_t)yc * rowb;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                row[k] = *reinterpret_cast<const f32x4*>(rp + xoff[k]);
+                row[k] = act_load4<BF>(reinterpret_cast<const float*>(rp + xoff[k]), 0);
                 if (!(vy && ((xin >> k) & 1u))) row[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
@@ -96,13 +98,14 @@ __global__ __launch_bounds__(256, 2) void post_rows_pk(PostParams p) {
                 const f32x2 t01 = sf.xy * nzq, t23 = sf.zw * nzq;
                 f32x2 a = (v01[q] + t01) + nb.xy, b = (v23[q] + t23) + nb.zw;
                 const f32x2 la = a * k02, lb = b * k02;
-                a = f32x2{fmaxf(a.x, la.x), fmaxf(a.y, la.y)};
-                b = f32x2{fmaxf(b.x, lb.x), fmaxf(b.y, lb.y)};
+                a = f32x2{max1(a.x, la.x), max1(a.y, la.y)};
+                b = f32x2{max1(b.x, lb.x), max1(b.y, lb.y)};
                 v01[q] = a; v23[q] = b;
                 const f32x4 o = {a.x, a.y, b.x, b.y};
-                f32x4* dst = reinterpret_cast<f32x4*>(orow + xoff[1 + q]);      // x0 + q is inside the image: its clamped offset is the real one
-                if (NT) __builtin_nontemporal_store(o, dst);
-                else *dst = o;
+                char* dst = orow + xoff[1 + q];      // x0 + q is inside the image: its clamped offset is the real one
+                if constexpr (BF) act_store4<true>(reinterpret_cast<float*>(dst), 0, o);
+                else if (NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst));
+                else *reinterpret_cast<f32x4*>(dst) = o;
             }
             // statistics per aligned x-quad and channel: s = (v0 + v1) + (v2 + v3), q = (v0 v0 + v1 v1) + (v2 v2 + v3 v3)
             const f32x2 s01 = (v01[0] + v01[1]) + (v01[2] + v01[3]);
@@ -144,8 +147,9 @@ int post_pk_mode() {
 }
 
 hipError_t launch_post_pk(const PostParams& q, dim3 grid, size_t lds, hipStream_t s) {
-    if (post_pk_mode() >= 2) hipLaunchKernelGGL(lean::post_rows_pk<true>, grid, dim3(256), lds, s, q);
-    else hipLaunchKernelGGL(lean::post_rows_pk<false>, grid, dim3(256), lds, s, q);
+    if (q.bf16) hipLaunchKernelGGL((lean::post_rows_pk<false, true>), grid, dim3(256), lds, s, q);
+    else if (post_pk_mode() >= 2) hipLaunchKernelGGL((lean::post_rows_pk<true, false>), grid, dim3(256), lds, s, q);
+    else hipLaunchKernelGGL((lean::post_rows_pk<false, false>), grid, dim3(256), lds, s, q);
     return hipGetLastError();
 }
 
