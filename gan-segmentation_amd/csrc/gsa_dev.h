@@ -10,6 +10,28 @@
 
 namespace gsa {
 
+// Diagnostic build only (make stamp): s_memtime stamps at the phase boundaries of the conv
+// kernel, summed per phase into ConvParams::stamps.  No stamp executes in the product build.
+#ifdef GSA_STAMP
+#define GSA_DBG_HOOKS 1
+#endif
+#ifdef GSA_STAMP
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_DECL unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP_FLUSH(nph) do { if (p.stamps && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < (nph); ++i_) atomicAdd(&p.stamps[i_], stamp_t[i_ + 1] - stamp_t[i_]); atomicAdd(&p.stamps[15], 1ull); } } while (0)
+#define TICK(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TSUM(acc, a, b) acc += (b) - (a)
+#define TFLUSH(idx, acc) do { if (p.stamps && (threadIdx.x & 63) == 0) atomicAdd(&p.stamps[idx], acc); } while (0)
+#else
+#define TICK(var) do {} while (0)
+#define TSUM(acc, a, b) do {} while (0)
+#define TFLUSH(idx, acc) do {} while (0)
+#define STAMP(i) do {} while (0)
+#define STAMP_DECL do {} while (0)
+#define STAMP_FLUSH(nph) do {} while (0)
+#endif
+
+
 constexpr int kDirectRows = 64;               // accumulator rows per sample of the "direct statistics" form (power of two)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

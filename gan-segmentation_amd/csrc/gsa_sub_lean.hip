@@ -288,11 +288,15 @@ __global__ __launch_bounds__(512, 2) void subpixel_lean(ConvParams p) {
         load_item(tr, er, cir);
     }
     __syncthreads();
+    unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, sw = 0, sl = 0, sm = 0, se = 0, sb = 0;      // diagnostic build only (make stamp)
+    (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)k5; (void)sw; (void)sl; (void)sm; (void)se; (void)sb;
     for (int it = 0; it < iters; ++it) {
+        TICK(k0);
         if (WST && it + 1 < iters) dma_block((it + 1) % nblk, (it + 1) & 1);      // the slot iteration it - 1 read: every wave is past its closing barrier
         bool stored = false, loaded = false;
         if (it < total_items) {
             if (it + 1 < total_items) write_item(tr, er, cir, (it + 1) & 1);
+            TICK(k1);
             STile t2 = tr; int e2c = er, ci2 = cir;
             if (it + 2 < total_items) {
                 loaded = true;
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_lean(ConvParams p) {
                 if (AFF && t2.n != n_tab) { fill_coefficients(t2.n); n_tab = t2.n; }
                 load_item(t2, e2c, ci2);
             }
+            TICK(k2);
             const float* a_buf = sA + ((it & 1) * KB) * SIMG;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
@@ -307,7 +312,9 @@ __global__ __launch_bounds__(512, 2) void subpixel_lean(ConvParams p) {
                 if (kb == 0 && cic == 0) mfma_block(std::true_type{}, a_buf + kb * SIMG, wslot);
                 else mfma_block(std::false_type{}, a_buf + kb * SIMG, wslot);
             }
+            TICK(k3);
             if (cic == nitem - 1) { epilogue(tc); stored = true; }
+            TICK(k4);
             tc = tr; ec = er; cic = cir; tr = t2; er = e2c; cir = ci2;
         }
         if (WST) {
@@ -320,7 +327,11 @@ __global__ __launch_bounds__(512, 2) void subpixel_lean(ConvParams p) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        TICK(k5);
+        if (it < total_items) { TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4); TSUM(sb, k4, k5); }
     }
+    TFLUSH(6, sw); TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(9, se); TFLUSH(10, sb);
+    TFLUSH(12, (unsigned long long)total_items); TFLUSH(15, 1ull);
 }
 
 constexpr int kMaxDev = 64;

@@ -46,9 +46,14 @@ struct Tile { int n, y0, x0; };
 // DB = false (NB = 1, GW = 1 only): ONE image buffer and two barriers per item -- the patch is read and transformed into registers, then the
 // buffer is refilled with the next item while the MFMAs run out of registers: 37 KB of LDS per workgroup, so THREE workgroups per CU when
 // the kernel also fits 168 registers (more waves instead of bigger items).
-template <int EPI, bool AFF, bool RES, int NB, int GW, bool DB = true>
+// PF = register sets of the activation prefetch: 1 = item it+2 is loaded while item it is multiplied (one item time between a load and its
+// use); 2 = item it+3 (two item times).  The 16 -> 16 layers at 1024^2 read and write 1.07 GB per launch -- they sit on the HBM roof, and
+// the stamps of the PF = 1 form (profiles/r05_stamps_lean.txt: write phase ~2100 of ~8100 cycles per item for six chunk stores) show the
+// staging writes WAITING for loads issued one item earlier: under a saturated memory system one item time (~3.5 us) does not cover a load.
+template <int EPI, bool AFF, bool RES, int NB, int GW, bool DB = true, int PF = 1>
 __global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_wino_lean(ConvParams p) {
     static_assert(DB || (NB == 1 && GW == 1), "single-buffered form: one block, one group");
+    static_assert(PF == 1 || (PF == 2 && DB), "two prefetch sets: the double-buffered form");
     constexpr int NTHR = 256 * GW, CIN = 16 * NB, COUT = 16 * GW;
     constexpr int NCH = (NPIX * 4 + NTHR - 1) / NTHR;      // staging rounds per item: 6 (5 full + 16 chunks) with 256 threads, 3 (2 full + 272) with 512
     constexpr bool kLastPartial = (NPIX * 4) % NTHR != 0;
@@ -94,12 +99,13 @@ __global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_
     auto edge_code = [&](const Tile& t) { return (t.y0 == 0 ? 1 : 0) | (t.y0 + 16 == H ? 2 : 0) | (t.x0 == 0 ? 4 : 0) | (t.x0 + 16 == W ? 8 : 0); };
     auto advance = [&](Tile& t) { t.x0 += 16; if (t.x0 == W) { t.x0 = 0; t.y0 += 16; if (t.y0 == H) { t.y0 = 0; t.n += 1; } } };
 
-    f32x4 ra[NCH];                            // the item in flight (loaded, not yet written to LDS)
+    f32x4 ra[PF][NCH];                        // the item(s) in flight (loaded, not yet written to LDS); item j lives in set j % PF
     f32x4 cA[NB], cB[NB];                     // AdaIN A / B of this thread's four channels of every block, for the sample being staged
 #pragma unroll
     for (int h = 0; h < NB; ++h) cA[h] = cB[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     int n_coef = -1;
-    auto load_item = [&](const Tile& t, int e, int cb) {
+    auto load_item = [&](auto set_tag, const Tile& t, int e, int cb) {
+        constexpr int S = decltype(set_tag)::value;
         const char* hb = reinterpret_cast<const char*>(p.src0) + ((((long)(t.n * H + t.y0) * W + t.x0) - (W + 1)) * CIN + cb * 16) * 4;
         // the last round holds fewer real chunks than threads; everybody issues it -- the idle lanes read the tile's first pixel
         if (e) {
@@ -107,14 +113,15 @@ __global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_
             for (int k = 0; k < NCH; ++k) {
                 const unsigned bad = (eflags >> (4 * k)) & (unsigned)e;
                 const unsigned off = s_off[k] + (bad ? safe_off - s_off[k] : 0u);
-                ra[k] = *reinterpret_cast<const f32x4*>(hb + off);
+                ra[S][k] = *reinterpret_cast<const f32x4*>(hb + off);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) ra[k] = *reinterpret_cast<const f32x4*>(hb + s_off[k]);
+            for (int k = 0; k < NCH; ++k) ra[S][k] = *reinterpret_cast<const f32x4*>(hb + s_off[k]);
         }
     };
-    auto write_item = [&](const Tile& t, int e, int cb, int buf) {
+    auto write_item = [&](auto set_tag, const Tile& t, int e, int cb, int buf) {
+        constexpr int S = decltype(set_tag)::value;
         float* img = sA + buf * IMG;
         if (AFF && t.n != n_coef) {           // wave-uniform: the first item and sample changes (a workgroup's range spans at most a few samples)
 #pragma unroll
@@ -131,14 +138,14 @@ __global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_
         if (e) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                const f32x4 v = AFF ? fma4(ra[k], kA, kB) : ra[k];
+                const f32x4 v = AFF ? fma4(ra[S][k], kA, kB) : ra[S][k];
                 const bool bad = ((eflags >> (4 * k)) & (unsigned)e) != 0;
                 if (!kLastPartial || k < NCH - 1 || l_off[NCH - 1] >= 0) *reinterpret_cast<f32x4*>(img + l_off[k]) = bad ? z : v;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < NCH; ++k)
-                if (!kLastPartial || k < NCH - 1 || l_off[NCH - 1] >= 0) *reinterpret_cast<f32x4*>(img + l_off[k]) = AFF ? fma4(ra[k], kA, kB) : ra[k];
+                if (!kLastPartial || k < NCH - 1 || l_off[NCH - 1] >= 0) *reinterpret_cast<f32x4*>(img + l_off[k]) = AFF ? fma4(ra[S][k], kA, kB) : ra[S][k];
         }
     };
 
@@ -306,36 +313,86 @@ __global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_
     auto next_item = [&](Tile& t, int& e, int& cb) {
         if (NB == 1 || ++cb == NB) { cb = 0; advance(t); e = edge_code(t); }
     };
-    load_item(tc, ec, 0);
-    write_item(tc, ec, 0, 0);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, PF - 1>;
+    // diagnostic build (make stamp) only: wave-cycle sums per phase -> ConvParams::stamps[6..10] (write, loads, transform + MFMA, epilogue, barrier)
+    unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, sw = 0, sl = 0, sm = 0, se = 0, sb = 0;
+    (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)k5; (void)sw; (void)sl; (void)sm; (void)se; (void)sb;
+    load_item(S0{}, tc, ec, 0);
+    write_item(S0{}, tc, ec, 0, 0);
     tr = tc; er = ec;
-    if (items > 1) { next_item(tr, er, cbr); load_item(tr, er, cbr); }
-    __syncthreads();
-    if constexpr (DB) {
-        for (int it = 0; it < items; ++it) {
+    if constexpr (PF == 2) {
+        // ---- two prefetch sets: item `it` in LDS buffer it & 1, items it+1 and it+2 in the register sets (it+1) & 1 and it & 1, item it+3 being loaded
+        Tile t2 = tc, t3; int e2c = ec, cb2 = 0, e3c, cb3;
+        if (items > 1) { next_item(tr, er, cbr); load_item(S1{}, tr, er, cbr); t2 = tr; e2c = er; cb2 = cbr; }
+        if (items > 2) { next_item(t2, e2c, cb2); load_item(S0{}, t2, e2c, cb2); }
+        __syncthreads();
+        auto body = [&](auto set_tag, int it) {      // set_tag: the register set of item it+1 (and of item it+3)
             const bool has_next = it + 1 < items;
-            if (has_next) write_item(tr, er, cbr, (it + 1) & 1);
+            TICK(k0);
+            if (has_next) write_item(set_tag, tr, er, cbr, (it + 1) & 1);
+            TICK(k1);
             if (cbc == NB - 1) epilogue_loads(tc);
-            Tile t2 = tr; int e2c = er, cb2 = cbr;
-            if (it + 2 < items) { next_item(t2, e2c, cb2); load_item(t2, e2c, cb2); }
+            t3 = t2; e3c = e2c; cb3 = cb2;
+            if (it + 3 < items) { next_item(t3, e3c, cb3); load_item(set_tag, t3, e3c, cb3); }
+            TICK(k2);
             if (NB == 1 || cbc == 0) multiply(std::true_type{}, it & 1, 0);
             else multiply(std::false_type{}, it & 1, cbc);
+            TICK(k3);
             if (cbc == NB - 1) {
                 epilogue(tc);
                 if (EPI == EPI_SYNTH && (!has_next || tr.n != tc.n)) flush_stats(tc.n);
             }
+            TICK(k4);
             __syncthreads();
+            TICK(k5);
+            TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4); TSUM(sb, k4, k5);
+            tc = tr; ec = er; cbc = cbr; tr = t2; er = e2c; cbr = cb2; t2 = t3; e2c = e3c; cb2 = cb3;
+        };
+        for (int it = 0; it < items; it += 2) {
+            body(S1{}, it);
+            if (it + 1 < items) body(S0{}, it + 1);
+        }
+        TFLUSH(6, sw); TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(9, se); TFLUSH(10, sb);
+        TFLUSH(12, (unsigned long long)items); TFLUSH(15, 1ull);
+        return;
+    }
+    if (items > 1) { next_item(tr, er, cbr); load_item(S0{}, tr, er, cbr); }
+    __syncthreads();
+    if constexpr (DB) {
+        for (int it = 0; it < items; ++it) {
+            const bool has_next = it + 1 < items;
+            TICK(k0);
+            if (has_next) write_item(S0{}, tr, er, cbr, (it + 1) & 1);
+            TICK(k1);
+            if (cbc == NB - 1) epilogue_loads(tc);
+            Tile t2 = tr; int e2c = er, cb2 = cbr;
+            if (it + 2 < items) { next_item(t2, e2c, cb2); load_item(S0{}, t2, e2c, cb2); }
+            TICK(k2);
+            if (NB == 1 || cbc == 0) multiply(std::true_type{}, it & 1, 0);
+            else multiply(std::false_type{}, it & 1, cbc);
+            TICK(k3);
+            if (cbc == NB - 1) {
+                epilogue(tc);
+                if (EPI == EPI_SYNTH && (!has_next || tr.n != tc.n)) flush_stats(tc.n);
+            }
+            TICK(k4);
+            __syncthreads();
+            TICK(k5);
+            TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4); TSUM(sb, k4, k5);
             tc = tr; ec = er; cbc = cbr; tr = t2; er = e2c; cbr = cb2;
         }
+        TFLUSH(6, sw); TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(9, se); TFLUSH(10, sb);
+        TFLUSH(12, (unsigned long long)items); TFLUSH(15, 1ull);
     } else {
         for (int it = 0; it < items; ++it) {
             const bool has_next = it + 1 < items;
             transform(0);                       // the patch of item `it` out of the one buffer, into registers
             __syncthreads();                    // every wave has read it
-            if (has_next) write_item(tr, er, 0, 0);
+            if (has_next) write_item(S0{}, tr, er, 0, 0);
             epilogue_loads(tc);
             Tile t2 = tr; int e2c = er, cb2 = 0;
-            if (it + 2 < items) { next_item(t2, e2c, cb2); load_item(t2, e2c, cb2); }
+            if (it + 2 < items) { next_item(t2, e2c, cb2); load_item(S0{}, t2, e2c, cb2); }
             mfmas(std::true_type{}, 0);
             epilogue(tc);
             if (EPI == EPI_SYNTH && (!has_next || tr.n != tc.n)) flush_stats(tc.n);
@@ -597,39 +654,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, sw = 0, sl = 0, sm = 0, se = 0, sb = 0;      // diagnostic build only (make stamp)
+    (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)k5; (void)sw; (void)sl; (void)sm; (void)se; (void)sb;
     for (int it = 0; it < items; ++it) {
         const bool has_next = it + 1 < items;
+        TICK(k0);
         if (has_next) {
             dma_weights(cbr, (it + 1) & 1);      // the panel buffer item it - 1 used: every wave is past that item's closing barrier
             write_item(tr, er, cbr, (it + 1) & 1);
         }
+        TICK(k1);
         if (cbc == nblk - 1) epilogue_loads(tc);
         Tile t2 = tr; int e2c = er, cb2 = cbr;
         if (it + 2 < items) { next_item(t2, e2c, cb2); load_item(t2, e2c, cb2); }
+        TICK(k2);
         if (cbc == 0) multiply(std::true_type{}, it & 1);
         else multiply(std::false_type{}, it & 1);
+        TICK(k3);
         if (cbc == nblk - 1) {
             epilogue(tc);
             if (EPI == EPI_SYNTH && (!has_next || tr.n != tc.n)) flush_stats(tc.n);
         }
+        TICK(k4);
         // this wave's DMA pieces have landed before anybody passes the barrier: they are older than the six loads of item it + 2 (in-order
         // completion), so at most six outstanding operations means the pieces are in LDS and the younger loads stay in flight; an
         // iteration that issued no such loads (the last two) waits for everything
         if (it + 2 < items) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        TICK(k5);
+        TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4); TSUM(sb, k4, k5);
         tc = tr; ec = er; cbc = cbr; tr = t2; er = e2c; cbr = cb2;
     }
+    TFLUSH(6, sw); TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(9, se); TFLUSH(10, sb);
+    TFLUSH(12, (unsigned long long)items); TFLUSH(15, 1ull);
 }
 
 constexpr int kMaxDev = 64;
 struct LeanState { bool attr_done = false; int cus = 0; };
 static std::mutex g_mu;
 
-template <int EPI, bool AFF, bool RES, int NB, int GW, bool DB = true>
+template <int EPI, bool AFF, bool RES, int NB, int GW, bool DB = true, int PF = 1>
 hipError_t launch_t(const ConvParams& p, int n, hipStream_t s) {
     static LeanState st[kMaxDev];
-    auto kern = conv3x3_wino_lean<EPI, AFF, RES, NB, GW, DB>;
+    auto kern = conv3x3_wino_lean<EPI, AFF, RES, NB, GW, DB, PF>;
     const size_t lds = sizeof(float) * ((DB ? 2 : 1) * IMG + GW * NB * SEG);
     if (p.device < 0 || p.device >= kMaxDev) return hipErrorInvalidDevice;
     int cus;
@@ -667,12 +735,30 @@ bool single_buffered() {
     return on;
 }
 
+// GSA_WINO_LEAN_PF=1 | 2: register sets of the activation prefetch of the 16 -> 16 kernels (speed only, same bits).  Measured equal (same box,
+// FFHQ batch 8: d.cvt_8 0.228 / 0.232 ms, d.main_7.b 0.260 / 0.257, g.1024.conv_2 0.257 / 0.259 with one / two sets): the wait in front of
+// the staging writes is the memory system's throughput (1.1-1.2 GB of traffic in 0.23 ms), not the distance between a load and its use.
+// Default: one set (24 registers fewer).
+int prefetch_sets() {
+    static const int pf = getenv("GSA_WINO_LEAN_PF") ? atoi(getenv("GSA_WINO_LEAN_PF")) : 1;
+    return pf == 2 ? 2 : 1;
+}
+
 template <int NB, int GW>
 hipError_t launch_shape(const ConvParams& p, int epi, int n, hipStream_t s) {
     if constexpr (NB == 1 && GW == 1) {
         if (epi == EPI_DEC && single_buffered()) {
             if (p.resid) return p.aff0 ? launch_t<EPI_DEC, true, true, 1, 1, false>(p, n, s) : launch_t<EPI_DEC, false, true, 1, 1, false>(p, n, s);
             return p.aff0 ? launch_t<EPI_DEC, true, false, 1, 1, false>(p, n, s) : launch_t<EPI_DEC, false, false, 1, 1, false>(p, n, s);
+        }
+    }
+    if constexpr (NB == 1 && GW == 1) {
+        if (prefetch_sets() == 2) {      // the HBM-bound 16 -> 16 layers: loads two items ahead of their use
+            if (epi == EPI_DEC) {
+                if (p.resid) return p.aff0 ? launch_t<EPI_DEC, true, true, 1, 1, true, 2>(p, n, s) : launch_t<EPI_DEC, false, true, 1, 1, true, 2>(p, n, s);
+                return p.aff0 ? launch_t<EPI_DEC, true, false, 1, 1, true, 2>(p, n, s) : launch_t<EPI_DEC, false, false, 1, 1, true, 2>(p, n, s);
+            }
+            if (epi == EPI_SYNTH) return p.aff0 ? launch_t<EPI_SYNTH, true, false, 1, 1, true, 2>(p, n, s) : launch_t<EPI_SYNTH, false, false, 1, 1, true, 2>(p, n, s);
         }
     }
     if (epi == EPI_DEC) {
@@ -745,8 +831,9 @@ const char* wino_lean_name(const ConvParams& p, int epi) {
         snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_stream<%d, %s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false");
         return buf;
     }
-    snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_lean<%d, %s, %s, %d, %d>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false",
-             p.resid ? "true" : "false", p.C0 / 16, p.Cout / 16);
+    const bool sb = p.C0 == 16 && epi == EPI_DEC && single_buffered();
+    snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_lean<%d, %s, %s, %d, %d, %s, %d>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false",
+             p.resid ? "true" : "false", p.C0 / 16, p.Cout / 16, sb ? "false" : "true", p.C0 == 16 && !sb ? prefetch_sets() : 1);
     return buf;
 }
 
