@@ -1153,8 +1153,22 @@ static int run_generator_pass(gsa_ctx* c, hipStream_t s, int n, const float* z, 
 }
 
 // feats_nhwc[i] / feat_aff[i]: decoder inputs in kernel layout (aff may be null)
+// the cvt convolution of decoder level i (networks_seg.py:64-79): conv3x3 + bias -> BN -> LeakyReLU on feature i
+static ConvParams cvt_params(gsa_ctx* c, int i, const float* src, const Aff* aff) {
+    const DecLevelDev& d = c->dl[i];
+    const int R = 4 << i;
+    ConvParams cp{}; cp.stamps = c->stamps; cp.zeros = c->zeros; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
+    cp.src0 = src; cp.aff0 = aff; cp.C0 = d.I;
+    cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
+    cp.wpk = d.cvt_w; cp.wino = d.cvt_u; cp.Cout = d.F; cp.out = c->cvt[i];
+    cp.bn_s = d.cvt_s; cp.bn_beta = d.cvt_beta;
+    return cp;
+}
+
+// feats_nhwc[i] / feat_aff[i]: decoder inputs in kernel layout (aff may be null).  rgb_img (gsa_generate only, the caller checked
+// wino_lean_fuses_torgb): the LAST level's cvt convolution also writes toRGB's uint8 image -- it stages the very tensor toRGB reads.
 static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsrc, const Aff* const* faff, float* logits,
-                       uint8_t* mask, int i_begin = 0, int i_end = -1, bool wait_levels = false) {
+                       uint8_t* mask, int i_begin = 0, int i_end = -1, bool wait_levels = false, uint8_t* rgb_img = nullptr) {
     const int nl = i_end < 0 ? c->d_n : i_end;
     const double N = n;
     char layer[64];
@@ -1165,13 +1179,14 @@ static int run_decoder(gsa_ctx* c, hipStream_t s, int n, const float* const* fsr
         const double px = N * R * R;
         if (wait_levels) HIP_TRY(hipStreamWaitEvent(s, c->ev_level[i], 0));   // generator feature i is ready
         {   // cvt_block: conv3x3+bias -> BN -> LeakyReLU (Dropout is identity at inference)
-            ConvParams cp{}; cp.stamps = c->stamps; cp.zeros = c->zeros; cp.dbg = c->dbg; cp.bf16 = c->bf16; cp.device = c->device; cp.prio = c->prio;
-            cp.src0 = fsrc[i]; cp.aff0 = faff ? faff[i] : nullptr; cp.C0 = d.I;
-            cp.Hs = R; cp.Ws = R; cp.H = R; cp.W = R;
-            cp.wpk = d.cvt_w; cp.wino = d.cvt_u; cp.Cout = d.F; cp.out = c->cvt[i];
-            cp.bn_s = d.cvt_s; cp.bn_beta = d.cvt_beta;
-            snprintf(layer, sizeof layer, "d.cvt_%d", i);
-            Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer, 2.0 * px * d.F * d.I * (conv_uses_wino43(cp, EPI_DEC, false) ? 2.25 : conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9), 4.0 * px * (d.I + d.F), 2.0 * px * d.F * d.I * 9);
+            ConvParams cp = cvt_params(c, i, fsrc[i], faff ? faff[i] : nullptr);
+            const bool with_rgb = rgb_img != nullptr && i == c->d_n - 1;
+            const int nc = c->gc.channels;
+            if (with_rgb) { cp.rgb_w = c->rgb_w; cp.rgb_b = c->rgb_b; cp.rgb_img = rgb_img; }
+            snprintf(layer, sizeof layer, with_rgb ? "d.cvt_%d+torgb" : "d.cvt_%d", i);
+            Launch lp(c, s, conv_kernel_name(cp, n, EPI_DEC, false), layer,
+                      2.0 * px * d.F * d.I * (conv_uses_wino43(cp, EPI_DEC, false) ? 2.25 : conv_uses_wino(cp, EPI_DEC, false) ? 4 : 9) + (with_rgb ? 2.0 * px * d.I * nc : 0.0),
+                      4.0 * px * (d.I + d.F) + (with_rgb ? px * nc : 0.0), 2.0 * px * d.F * d.I * 9 + (with_rgb ? 2.0 * px * d.I * nc : 0.0));
             HIP_TRY(launch_conv3x3(cp, EPI_DEC, false, n, s));
         }
         if (!d.is_last) {
@@ -1286,13 +1301,22 @@ int gsa_generate(gsa_ctx* c, void* stream, int32_t n, const float* z, const floa
         HIP_TRY(hipEventRecord(c->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     }
-    if (int rc = run_generator(c, s, n, z, noise, nullptr, img, nullptr, ns > 0)) return rc;
+    // toRGB reads the generator's last feature with its AdaIN coefficients -- exactly what the decoder's last cvt convolution stages.  Where
+    // that convolution is the lean 16 -> 16 kernel it writes the uint8 image as well (round 5): one 0.5 GB read per FFHQ batch of 8 less.
+    // The last decoder level always runs on the caller's stream, behind the generator.
+    bool fuse_rgb = false;
+    if (img && ns <= c->d_n - 1) {
+        const int last = c->d_n - 1;
+        ConvParams cp = cvt_params(c, last, fsrc[last], faff[last]);
+        fuse_rgb = conv_fuses_torgb(cp, EPI_DEC, false, c->gc.channels);
+    }
+    if (int rc = run_generator(c, s, n, z, noise, nullptr, fuse_rgb ? nullptr : img, nullptr, ns > 0)) return rc;
     if (ns > 0) {
         if (int rc = run_decoder(c, c->side, n, fsrc, faff, nullptr, nullptr, 0, ns, true)) return rc;
         HIP_TRY(hipEventRecord(c->ev_join, c->side));
         HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     }
-    return run_decoder(c, s, n, fsrc, faff, nullptr, mask, ns, -1, false);
+    return run_decoder(c, s, n, fsrc, faff, nullptr, mask, ns, -1, false, fuse_rgb ? img : nullptr);
 }
 
 int gsa_fill_inputs(gsa_ctx* c, void* stream, int32_t n, uint64_t seed, uint64_t first_index, float* z, float* const* noise,

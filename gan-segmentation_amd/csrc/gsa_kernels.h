@@ -57,6 +57,9 @@ struct ConvParams {
     // the AdaIN coefficients itself instead of partial rows -- the finalize launch of the layer is skipped (fin_aff null: not fused)
     const float* fin_style; int fin_style_stride; const float* fin_gamma; const float* fin_beta; Aff* fin_aff; unsigned* fin_flags;
     const float* zeros;           // >= 64 bytes of zeros in device memory: what conv3x3_wino43's LDS-DMA reads for a pixel outside the image
+    // toRGB fused into the convolution that stages the SAME tensor with the SAME AdaIN (round 5: the decoder's last cvt conv reads the generator's
+    // last feature, as toRGB does): rgb_img non-null = also write the uint8 image (N, H, W, 3) from the staged, AdaIN-applied tile
+    const float* rgb_w; const float* rgb_b; uint8_t* rgb_img;
 };
 
 struct PostParams {
@@ -92,6 +95,8 @@ bool conv_uses_wino(const ConvParams& p, int epi, bool shortcut);   // true: Win
 bool wino_lean_applies(const ConvParams& p, int epi);
 const char* wino_lean_name(const ConvParams& p, int epi);
 hipError_t launch_wino_lean(const ConvParams& p, int epi, int n, hipStream_t s);
+bool wino_lean_fuses_torgb(const ConvParams& p, int epi, int nc);      // the lean kernel's own conditions
+bool conv_fuses_torgb(const ConvParams& p, int epi, bool shortcut, int nc);      // true: launch_conv3x3 on p (rgb_* set) also produces toRGB's uint8 image
 // gsa_sub_lean.hip (round 5): subpixel_res<..., WINO> (fp32) in a leaner instruction stream -- speed only, same bits (GSA_SUB_LEAN=0: subpixel_res)
 bool subpixel_lean_applies(const ConvParams& p, int nt, int epi, bool sc, int kb, bool wst);
 const char* subpixel_lean_name(const ConvParams& p, int nt, int epi, bool sc, int kb, bool wst);

@@ -4176,6 +4176,14 @@ static hipError_t launch_wino(const ConvParams& p, int epi, int n, hipStream_t s
 #undef GSA_W
 }
 
+// true: launch_conv3x3(p, epi, sc) with p.rgb_* set also writes toRGB's uint8 image -- i.e. the call reaches the lean 16 -> 16 kernel (an
+// experiment switch that takes the layer elsewhere, or the F(4x4,3x3) form, rules it out: they know nothing of rgb_img)
+bool conv_fuses_torgb(const ConvParams& p, int epi, bool sc, int nc) {
+    if (!conv_uses_wino(p, epi, sc) || conv_uses_wino43(p, epi, sc)) return false;
+    if ((wino_dma(p, epi) && wino_nt(p) == 1) || wino_tw(p) == 2) return false;
+    return wino_lean_fuses_torgb(p, epi, nc);
+}
+
 // exact C++ name of the instantiation launch_conv3x3 picks (profile labels spell kernels as rocprofv3 prints them)
 const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
     static thread_local char buf[128];

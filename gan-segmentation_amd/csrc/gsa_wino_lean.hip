@@ -50,8 +50,13 @@ struct Tile { int n, y0, x0; };
 // use); 2 = item it+3 (two item times).  The 16 -> 16 layers at 1024^2 read and write 1.07 GB per launch -- they sit on the HBM roof, and
 // the stamps of the PF = 1 form (profiles/r05_stamps_lean.txt: write phase ~2100 of ~8100 cycles per item for six chunk stores) show the
 // staging writes WAITING for loads issued one item earlier: under a saturated memory system one item time (~3.5 us) does not cover a load.
-template <int EPI, bool AFF, bool RES, int NB, int GW, bool DB = true, int PF = 1>
+// RGB (16 -> 16, decoder epilogue, AdaIN source): toRGB + _transform_gan_back (reference networks_stylegan.py:118-126, image_generator.py:76-84) of
+// the SAME tile out of the staged LDS image -- the decoder's last cvt conv and toRGB both read the generator's last feature with the same AdaIN
+// coefficients, and the staged value fmaf(x, A, B) is exactly what toRGB's chain starts from; thread = pixel of the 16x16 tile, the canonical
+// k-ascending fmaf chain per colour, the uint8 bytes of four pixels packed into three dwords per lane quad.  Saves a 0.5 GB read per launch.
+template <int EPI, bool AFF, bool RES, int NB, int GW, bool DB = true, int PF = 1, bool RGB = false>
 __global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_wino_lean(ConvParams p) {
+    static_assert(!RGB || (NB == 1 && GW == 1 && DB && AFF && EPI == EPI_DEC), "fused toRGB: the 16 -> 16 decoder kernel with an AdaIN source");
     static_assert(DB || (NB == 1 && GW == 1), "single-buffered form: one block, one group");
     static_assert(PF == 1 || (PF == 2 && DB), "two prefetch sets: the double-buffered form");
     constexpr int NTHR = 256 * GW, CIN = 16 * NB, COUT = 16 * GW;
@@ -202,6 +207,36 @@ __global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_
         }
     };
 
+    auto torgb = [&](const Tile& t, int buf) {      // after the item's multiply, before its closing barrier: the image buffer still holds the tile
+        const float* px = sA + buf * IMG + ((tid >> 4) + 1) * RS + ((tid & 15) + 1) * 16;
+        f32x4 f4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f4[k] = *reinterpret_cast<const f32x4*>(px + 4 * k);
+        // the 48 weights and 3 biases are read through the constant address space: wave-uniform scalar loads (as plain global pointers next to
+        // the kernel's own stores they became twelve vector loads per item)
+        const __attribute__((address_space(4))) float* cw = (const __attribute__((address_space(4))) float*)p.rgb_w;
+        const __attribute__((address_space(4))) float* cb = (const __attribute__((address_space(4))) float*)p.rgb_b;
+        float a3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) a3[o] = fmaf(f4[c >> 2][c & 3], cw[o * 16 + c], a3[o]);
+        unsigned pk = 0;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float u = ((a3[o] + cb[o]) + 1.0f) * 0.5f;
+            u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+            pk |= (unsigned)(uint8_t)(255.0f * u) << (8 * o);
+        }
+        // four pixels of a lane quad = 12 bytes = three dwords: lane j of the quad stores dword j = (P_j >> 8j) | (P_{j+1} << (24 - 8j))
+        const unsigned nxt = (unsigned)__builtin_amdgcn_mov_dpp((int)pk, 0xF9, 0xF, 0xF, true);      // quad_perm [1, 2, 3, 3]
+        const int j = tid & 3;
+        const unsigned dw = (pk >> (8 * j)) | (nxt << (24 - 8 * j));
+        if (j < 3) {
+            const long pix = ((long)(t.n * H + t.y0 + (tid >> 4)) * W + t.x0 + (tid & 12));      // first pixel of the quad
+            *reinterpret_cast<unsigned*>(p.rgb_img + pix * 3 + 4 * j) = dw;
+        }
+    };
     f32x4 acc[16], V[16];
     auto transform = [&](int buf) {
         const float* a_img = sA + buf * IMG + pbase;
@@ -372,6 +407,7 @@ __global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_
             if (NB == 1 || cbc == 0) multiply(std::true_type{}, it & 1, 0);
             else multiply(std::false_type{}, it & 1, cbc);
             TICK(k3);
+            if constexpr (RGB) torgb(tc, it & 1);
             if (cbc == NB - 1) {
                 epilogue(tc);
                 if (EPI == EPI_SYNTH && (!has_next || tr.n != tc.n)) flush_stats(tc.n);
@@ -694,10 +730,10 @@ constexpr int kMaxDev = 64;
 struct LeanState { bool attr_done = false; int cus = 0; };
 static std::mutex g_mu;
 
-template <int EPI, bool AFF, bool RES, int NB, int GW, bool DB = true, int PF = 1>
+template <int EPI, bool AFF, bool RES, int NB, int GW, bool DB = true, int PF = 1, bool RGB = false>
 hipError_t launch_t(const ConvParams& p, int n, hipStream_t s) {
     static LeanState st[kMaxDev];
-    auto kern = conv3x3_wino_lean<EPI, AFF, RES, NB, GW, DB, PF>;
+    auto kern = conv3x3_wino_lean<EPI, AFF, RES, NB, GW, DB, PF, RGB>;
     const size_t lds = sizeof(float) * ((DB ? 2 : 1) * IMG + GW * NB * SEG);
     if (p.device < 0 || p.device >= kMaxDev) return hipErrorInvalidDevice;
     int cus;
@@ -753,6 +789,10 @@ hipError_t launch_shape(const ConvParams& p, int epi, int n, hipStream_t s) {
         }
     }
     if constexpr (NB == 1 && GW == 1) {
+        if (p.rgb_img != nullptr) {      // the caller checked wino_lean_fuses_torgb
+            if (epi != EPI_DEC || !p.aff0 || p.resid) return hipErrorInvalidValue;
+            return launch_t<EPI_DEC, true, false, 1, 1, true, 1, true>(p, n, s);
+        }
         if (prefetch_sets() == 2) {      // the HBM-bound 16 -> 16 layers: loads two items ahead of their use
             if (epi == EPI_DEC) {
                 if (p.resid) return p.aff0 ? launch_t<EPI_DEC, true, true, 1, 1, true, 2>(p, n, s) : launch_t<EPI_DEC, false, true, 1, 1, true, 2>(p, n, s);
@@ -825,6 +865,13 @@ bool wino_lean_applies(const ConvParams& p, int epi) {
     return true;
 }
 
+// toRGB rides on the decoder's last cvt conv when that conv is the 16 -> 16 lean kernel reading an AdaIN source, 3 colours (GSA_FUSE_RGB=0: never)
+bool wino_lean_fuses_torgb(const ConvParams& p, int epi, int nc) {
+    static const bool enabled = !(getenv("GSA_FUSE_RGB") && atoi(getenv("GSA_FUSE_RGB")) == 0);
+    return enabled && nc == 3 && epi == EPI_DEC && p.C0 == 16 && p.Cout == 16 && p.aff0 != nullptr && p.resid == nullptr && !p.bf16 &&
+           wino_lean_applies(p, epi) && !single_buffered();
+}
+
 const char* wino_lean_name(const ConvParams& p, int epi) {
     static thread_local char buf[112];
     if (p.C0 >= 64) {
@@ -832,8 +879,9 @@ const char* wino_lean_name(const ConvParams& p, int epi) {
         return buf;
     }
     const bool sb = p.C0 == 16 && epi == EPI_DEC && single_buffered();
-    snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_lean<%d, %s, %s, %d, %d, %s, %d>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false",
-             p.resid ? "true" : "false", p.C0 / 16, p.Cout / 16, sb ? "false" : "true", p.C0 == 16 && !sb ? prefetch_sets() : 1);
+    const bool rgbf = p.rgb_img != nullptr;
+    snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_lean<%d, %s, %s, %d, %d, %s, %d, %s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false",
+             p.resid ? "true" : "false", p.C0 / 16, p.Cout / 16, sb ? "false" : "true", p.C0 == 16 && !sb && !rgbf ? prefetch_sets() : 1, rgbf ? "true" : "false");
     return buf;
 }
 
