@@ -663,7 +663,10 @@ def main():
             t1 = time.perf_counter()
             out["end_to_end"] = measure_end_to_end(gen, B, max(4, min(args.steps, 20)), dev)
             if args.gan == "ffhq" and args.precision == "fp32" and args.job_samples > 0:
-                out["end_to_end"].update(measure_generate_job("ffhq", args.job_samples, 32, dev))
+                try:
+                    out["end_to_end"].update(measure_generate_job("ffhq", args.job_samples, 32, dev))
+                except Exception as e:      # a full or read-only temporary directory must not cost the driver its line
+                    out["end_to_end"]["generate_job_error"] = "%s: %s" % (type(e).__name__, e)
             sec = []
             if (args.gan, args.precision, B) != ("bedrooms", "fp32", 64):
                 sec.append(measure_secondary("bedrooms", 64, "fp32", 10, 2, dev))      # BASELINE.json configs[3]
