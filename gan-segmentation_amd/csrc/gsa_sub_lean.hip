@@ -37,9 +37,16 @@ __device__ __forceinline__ void mfma_settle9(f32x4 (&a)[9]) {
     asm("s_nop 7\n\ts_nop 3" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]));
 }
 
-template <int NT, int EPI, bool SC, bool AFF, int KB, bool WST>
+// CNT (resident panel only): the two halves of the workgroup share nothing but the read-only panel, so nothing forces them through ONE
+// eight-wave barrier per item.  Each half hands its image buffers over through two LDS counters of its own (arrivals after an item's
+// staging stores / after its last LDS read) and the images form a ring of THREE: the buffer a wave fills was read two items ago, the buffer
+// it reads was filled one item ago -- both conditions are a whole item old when they are checked, so a wave waits only for a partner that
+// lags a full item behind, and the four waves of a half drift apart instead of meeting at the slowest one every item.
+template <int NT, int EPI, bool SC, bool AFF, int KB, bool WST, bool CNT = false>
 __global__ __launch_bounds__(512, 2) void subpixel_lean(ConvParams p) {
     static_assert(!WST || KB == 1, "streamed weights: one channel block per item");
+    static_assert(!CNT || !WST, "counter hand-over: the resident-panel form");
+    constexpr int NBUF = CNT ? 3 : 2;
     constexpr int NSTORES = 4 * NT + (SC ? NT : 0);      // global stores of one epilogue per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nblk0 = p.C0 >> 4, nblk = (p.C0 + p.C1) >> 4, nitem = nblk / KB;
@@ -49,11 +56,13 @@ __global__ __launch_bounds__(512, 2) void subpixel_lean(ConvParams p) {
     float* const sW = smem;                                           // [wblk][NT][SSEG]
     float* const sS = sW + wblk * NT * SSEG;                           // SC: [wblk][NT][STS]
     float* const sAall = sS + (SC ? wblk * NT * STS : 0);
-    float* const sA = sAall + half * (2 * KB * SIMG);                  // this half: [2][KB][SIMG]
-    float* const sC = sAall + 4 * KB * SIMG + half * (2 * nblk0 * 32); // AFF, this half: [2 (sample parity)][nblk0][A x 16 | B x 16]
+    float* const sA = sAall + half * (NBUF * KB * SIMG);               // this half: [NBUF][KB][SIMG]
     const int t8 = threadIdx.x & 255, lane = t8 & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t8 >> 6);          // the wave's parity class
     const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // AFF: [2 (sample parity)][nblk0][A x 16 | B x 16] per half -- per WAVE with CNT (each wave fills its own copy: no hand-over between waves)
+    float* const sC = sAall + 2 * NBUF * KB * SIMG + (CNT ? wave8 : half) * (2 * nblk0 * 32);
+    unsigned* const sCnt = reinterpret_cast<unsigned*>(sAall + 2 * NBUF * KB * SIMG + (AFF ? (CNT ? 8 : 2) * 2 * nblk0 * 32 : 0)) + half * 8;   // CNT: {written[4], read[4]}
     const int py = wave >> 1, px = wave & 1;
     const int i16 = lane & 15, kq = lane >> 4, part = t8 & 3;
     const int H = p.H, W = p.W, Hs = p.Hs, Ws = p.Ws, COUT = p.Cout;
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_lean(ConvParams p) {
     // iteration publishes them; the slot of the previous sample is still being read meanwhile)
     auto fill_coefficients = [&](int n) {
         float* tab = sC + (n & 1) * (nblk0 * 32);
-        for (int e = t8; e < p.C0; e += 256) {
+        for (int e = CNT ? lane : t8; e < p.C0; e += CNT ? 64 : 256) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(p.aff0 + (size_t)n * p.C0 + e);      // (mean, A, B, -)
             tab[(e >> 4) * 32 + (e & 15)] = a[1];
             tab[(e >> 4) * 32 + 16 + (e & 15)] = a[2];
@@ -279,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void subpixel_lean(ConvParams p) {
     if (AFF) fill_coefficients(tc.n);
     if (total_items > 0) load_item(tc, ec, 0);
     if (WST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ring slot 0
+    if (CNT && t8 < 8) sCnt[t8] = t8 < 4 ? 1u : 0u;                   // item 0 counts as staged (the barrier below publishes it)
     __syncthreads();                                                  // weight panel and coefficient table visible
     if (total_items > 0) write_item(tc, ec, 0, 0);
     tr = tc; er = ec;
@@ -290,6 +300,57 @@ __global__ __launch_bounds__(512, 2) void subpixel_lean(ConvParams p) {
     __syncthreads();
     unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, sw = 0, sl = 0, sm = 0, se = 0, sb = 0;      // diagnostic build only (make stamp)
     (void)k0; (void)k1; (void)k2; (void)k3; (void)k4; (void)k5; (void)sw; (void)sl; (void)sm; (void)se; (void)sb;
+    if constexpr (CNT) {
+        // one progress word per wave and kind (a sum over the waves would let a wave that runs ahead stand in for one that lags):
+        // written[w] = items wave w has staged, read[w] = items it has finished reading; a condition holds when the slowest wave meets it
+        unsigned n_written = 1, n_read = 0;
+        auto publish = [&](unsigned* c, unsigned v) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's LDS stores / reads are done before it says so
+            if (lane == 0) __hip_atomic_store(c + wave, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto wait_for = [&](unsigned* c, int target) {
+            for (;;) {
+                const u32x4 v = *reinterpret_cast<volatile u32x4*>(c);
+                const int lo = (int)min(min(v[0], v[1]), min(v[2], v[3]));
+                if (lo >= target) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        for (int it = 0; it < total_items; ++it) {
+            TICK(k0);
+            if (it + 1 < total_items) {
+                wait_for(sCnt + 4, it - 1);                          // items <= it - 2 are read by everybody: buffer (it + 1) % 3 is free
+                write_item(tr, er, cir, (it + 1) % 3);
+                publish(sCnt, ++n_written);
+            }
+            TICK(k1);
+            STile t2 = tr; int e2c = er, ci2 = cir;
+            if (it + 2 < total_items) {
+                next_item(t2, e2c, ci2);
+                if (AFF && t2.n != n_tab) { fill_coefficients(t2.n); n_tab = t2.n; }
+                load_item(t2, e2c, ci2);
+            }
+            TICK(k2);
+            wait_for(sCnt, it + 1);                                  // item it is complete in its buffer (it was staged one item ago)
+            const float* a_buf = sA + ((it % 3) * KB) * SIMG;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int wslot = cic * KB + kb;
+                if (kb == 0 && cic == 0) mfma_block(std::true_type{}, a_buf + kb * SIMG, wslot);
+                else mfma_block(std::false_type{}, a_buf + kb * SIMG, wslot);
+            }
+            publish(sCnt + 4, ++n_read);
+            TICK(k3);
+            if (cic == nitem - 1) epilogue(tc);
+            TICK(k4);
+            TSUM(sw, k0, k1); TSUM(sl, k1, k2); TSUM(sm, k2, k3); TSUM(se, k3, k4);
+            tc = tr; ec = er; cic = cir; tr = t2; er = e2c; cir = ci2;
+        }
+        TFLUSH(6, sw); TFLUSH(7, sl); TFLUSH(8, sm); TFLUSH(9, se); TFLUSH(10, sb);
+        TFLUSH(12, (unsigned long long)total_items); TFLUSH(15, 1ull);
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
         TICK(k0);
         if (WST && it + 1 < iters) dma_block((it + 1) % nblk, (it + 1) & 1);      // the slot iteration it - 1 read: every wave is past its closing barrier
@@ -338,12 +399,18 @@ constexpr int kMaxDev = 64;
 struct SubState { bool attr_done = false; };
 static std::mutex g_sub_mu;
 
-template <int NT, int EPI, bool SC, bool AFF, int KB, bool WST>
+// LDS bytes of an instantiation (cnt: the three-buffer counter form)
+size_t sub_lds(const ConvParams& q, int nt, bool sc, bool aff, int kb, bool wst, bool cnt) {
+    const int nblk0 = q.C0 / 16, nblk = (q.C0 + q.C1) / 16, wblk = wst ? 2 : nblk;
+    return sizeof(float) * ((size_t)wblk * nt * SSEG + (sc ? (size_t)wblk * nt * STS : 0) + 2 * (cnt ? 3 : 2) * kb * SIMG +
+                            (aff ? (cnt ? 8 : 2) * 2 * nblk0 * 32 : 0)) + (cnt ? 64 : 0);
+}
+
+template <int NT, int EPI, bool SC, bool AFF, int KB, bool WST, bool CNT = false>
 hipError_t launch_k(const ConvParams& q, dim3 grid, hipStream_t s) {
     static SubState st[kMaxDev];
-    auto kern = subpixel_lean<NT, EPI, SC, AFF, KB, WST>;
-    const int nblk0 = q.C0 / 16, nblk = (q.C0 + q.C1) / 16, wblk = WST ? 2 : nblk;
-    const size_t lds = sizeof(float) * ((size_t)wblk * NT * SSEG + (SC ? (size_t)wblk * NT * STS : 0) + 4 * KB * SIMG + (AFF ? 4 * nblk0 * 32 : 0));
+    auto kern = subpixel_lean<NT, EPI, SC, AFF, KB, WST, CNT>;
+    const size_t lds = sub_lds(q, NT, SC, AFF, KB, WST, CNT);
     if (lds > 160 * 1024 || q.device < 0 || q.device >= kMaxDev) return hipErrorInvalidValue;
     {
         std::lock_guard<std::mutex> lk(g_sub_mu);
@@ -360,6 +427,13 @@ hipError_t launch_k(const ConvParams& q, dim3 grid, hipStream_t s) {
 template <int NT, int EPI, bool SC, bool AFF>
 hipError_t launch_shape(const ConvParams& q, int kb, bool wst, dim3 grid, hipStream_t s) {
     if (wst) return launch_k<NT, EPI, SC, AFF, 1, true>(q, grid, s);
+#if GSA_EXPERIMENTS
+    // GSA_SUB_CNT=1 (experiments build): per-half progress words with a ring of three images instead of the eight-wave barrier (resident
+    // panel; same bits).  Measured 2.3 % slower over the whole step (1290 against 1320 pairs/s on one box): see DESIGN.md section 5.
+    static const bool cnt_on = getenv("GSA_SUB_CNT") && atoi(getenv("GSA_SUB_CNT")) != 0;
+    if (cnt_on && sub_lds(q, NT, SC, AFF, kb, false, true) <= 160 * 1024)
+        return kb == 2 ? launch_k<NT, EPI, SC, AFF, 2, false, true>(q, grid, s) : launch_k<NT, EPI, SC, AFF, 1, false, true>(q, grid, s);
+#endif
     return kb == 2 ? launch_k<NT, EPI, SC, AFF, 2, false>(q, grid, s) : launch_k<NT, EPI, SC, AFF, 1, false>(q, grid, s);
 }
 
@@ -371,10 +445,7 @@ bool subpixel_lean_applies(const ConvParams& p, int nt, int epi, bool sc, int kb
     static const bool enabled = !(getenv("GSA_SUB_LEAN") && atoi(getenv("GSA_SUB_LEAN")) == 0);
     if (!enabled || p.bf16 || (nt != 1 && nt != 2) || (epi != EPI_RAW && epi != EPI_DEC) || (sc && epi != EPI_DEC)) return false;
     if (p.aff0 != nullptr && p.C1 != 0) return false;
-    const int nblk0 = p.C0 / 16, nblk = (p.C0 + p.C1) / 16, wblk = wst ? 2 : nblk;
-    const size_t lds = sizeof(float) * ((size_t)wblk * nt * lean::SSEG + (sc ? (size_t)wblk * nt * lean::STS : 0) + 4 * kb * lean::SIMG +
-                                        (p.aff0 ? 4 * nblk0 * 32 : 0));
-    return lds <= 160 * 1024;
+    return lean::sub_lds(p, nt, sc, p.aff0 != nullptr, kb, wst, false) <= 160 * 1024;
 }
 
 const char* subpixel_lean_name(const ConvParams& p, int nt, int epi, bool sc, int kb, bool wst) {
