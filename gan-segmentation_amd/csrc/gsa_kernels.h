@@ -93,7 +93,7 @@ bool conv_uses_wino(const ConvParams& p, int epi, bool shortcut);   // true: Win
 // gsa_wino_lean.hip (round 5): the Winograd layers with one 16-channel input block and one 16-channel output group in a leaner
 // instruction stream -- speed only, the same arithmetic and bits as conv3x3_wino (GSA_WINO_LEAN=0 keeps conv3x3_wino)
 bool wino_lean_applies(const ConvParams& p, int epi);
-const char* wino_lean_name(const ConvParams& p, int epi);
+const char* wino_lean_name(const ConvParams& p, int epi, int n);
 hipError_t launch_wino_lean(const ConvParams& p, int epi, int n, hipStream_t s);
 bool wino_lean_fuses_torgb(const ConvParams& p, int epi, int nc);      // the lean kernel's own conditions
 bool conv_fuses_torgb(const ConvParams& p, int epi, bool shortcut, int nc);      // true: launch_conv3x3 on p (rgb_* set) also produces toRGB's uint8 image

@@ -4191,7 +4191,7 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_wino43<%d>(gsa::ConvParams)", epi);
         return buf;
     }
-    if (conv_uses_wino(p, epi, sc) && !(wino_dma(p, epi) && wino_nt(p) == 1) && wino_tw(p) != 2 && wino_lean_applies(p, epi)) return wino_lean_name(p, epi);
+    if (conv_uses_wino(p, epi, sc) && !(wino_dma(p, epi) && wino_nt(p) == 1) && wino_tw(p) != 2 && wino_lean_applies(p, epi)) return wino_lean_name(p, epi, n);
     if (conv_uses_wino(p, epi, sc) && wino_dma(p, epi) && wino_nt(p) == 1) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_wino_dma<%d, %s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false");
         return buf;

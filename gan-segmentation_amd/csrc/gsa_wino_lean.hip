@@ -447,14 +447,24 @@ __global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_
 // a 4 KB LDS table as (A x 16 | B x 16) per block -- two LDS reads per item instead of four global loads of (mean, A, B, -) entries -- and are
 // applied with packed fma; wave-uniform global bases; border flags in one word; weights as the A operand, so the epilogue of the tile's last
 // block is the transposition-free packed one of conv3x3_wino_lean; the chains of a tile's first block start from the inline constant 0.
-template <int EPI, bool AFF>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
+// NT = 2: the workgroup owns TWO output groups (blockIdx.y = group pair): one staged image, one input transform, 128 MFMAs per item and wave.
+// 128 accumulator registers: one wave per SIMD with the whole register file (LDS: 106 KB, one workgroup per CU).
+// IL: the item's vector-memory instructions (the next item's weight DMA, the loads of the item after it) are issued INSIDE the MFMA stream
+// of the current item instead of in phases of their own.  The stamps of the phased form charge 1.3-2.0 k cycles per item to those phases
+// although nothing in them waits for data: every wave of the CU issues its 1 KB instructions at the same moment and the texture-address
+// path takes them at 64 B per clock (an item's 37-53 KB are 600-850 cycles per CU) -- time in which no MFMA is issued.  Issued between the
+// MFMAs of frequency rows 0 and 2 that time is the matrix pipe's; the weight reads of a row are issued one row ahead by hand, because the
+// scheduling barriers that pin the memory instructions also stop the compiler from hoisting them.
+// (A further form, IL = 2 -- the item's barrier moved between the staging stores and the MFMAs so that the next item's patch reads could be
+// issued in front of the MFMAs and transformed behind them -- was bit-exact and 12 % slower without spills, 55 % slower with them: DESIGN.md 5.)
+template <int EPI, bool AFF, int NT = 1, int IL = 0>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino_stream(ConvParams p) {
     constexpr int NCH = 6;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const sA = smem;                       // [2][IMG]
-    float* const sB = smem + 2 * IMG;             // [2][SEG]
-    float* const sE = sB + 2 * SEG;               // [4][16]: nscale | nbias | bn_s | bn_beta of the group's 16 output channels
-    float* const sC = sE + 64;                    // [nblk][32]: A of the block's 16 channels, then B (the sample being staged)
+    float* const sB = smem + 2 * IMG;             // [2][NT][SEG]
+    float* const sE = sB + 2 * NT * SEG;          // [NT][4][16]: nscale | nbias | bn_s | bn_beta of the group's 16 output channels
+    float* const sC = sE + 64 * NT;               // [nblk][32]: A of the block's 16 channels, then B (the sample being staged)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4, part = tid & 3;
@@ -482,19 +492,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
     auto advance = [&](Tile& t) { t.x0 += 16; if (t.x0 == W) { t.x0 = 0; t.y0 += 16; if (t.y0 == H) { t.y0 = 0; t.n += 1; } } };
 
     f32x4 ra[NCH];                                // the item in flight: this thread's activation chunks
-    const float* const wgrp = p.wpk + (size_t)g * nblk * SEG + lane * 4;
-    // the item's weight block: pieces wave, wave + 4, wave + 8, wave + 12 of 1 KB each, straight into the LDS panel
+    const float* const wgrp = p.wpk + (size_t)g * NT * nblk * SEG + lane * 4;
+    // the item's weight block(s): pieces wave, wave + 4, wave + 8, wave + 12 of 1 KB each per group, straight into the LDS panel
     auto dma_weights = [&](int cb, int buf) {
-        const float* wb = wgrp + (size_t)cb * SEG;
+#ifdef GSA_DBG_HOOKS
+        if (p.dbg & 16) cb = 0;      // diagnostic build only (WRONG results): the weight stream stays in L2
+#endif
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int piece = wave + 4 * j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + piece * 256),
-                                             (__attribute__((address_space(3))) void*)(sB + buf * SEG + piece * 256), 16, 0, 0);
+        for (int ct = 0; ct < NT; ++ct) {
+            const float* wb = wgrp + ((size_t)ct * nblk + cb) * SEG;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int piece = wave + 4 * j;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + piece * 256),
+                                                 (__attribute__((address_space(3))) void*)(sB + (buf * NT + ct) * SEG + piece * 256), 16, 0, 0);
+            }
         }
     };
     auto load_item = [&](const Tile& t, int e, int cb) {
         const char* hb = reinterpret_cast<const char*>(p.src0) + ((((long)(t.n * H + t.y0) * W + t.x0) - (W + 1)) * CIN + cb * 16) * 4;
+#ifdef GSA_DBG_HOOKS
+        if (p.dbg & 32) hb = reinterpret_cast<const char*>(p.src0) + ((long)(W + 1) * CIN) * 4;      // diagnostic build only (WRONG results): one input tile, block 0
+#endif
         if (e) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
@@ -544,32 +563,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
     const int qy = wave >> 1, qx = wave & 1;
     const int pbase = (qy * 8 + 2 * wty) * RS + (qx * 8 + 2 * wtx) * 16 + kq * 4;
     const int bbase = (kq * 16 + i16) * 4;
-    const int co4 = g * 16 + kq * 4;
+    const int co4 = g * NT * 16 + kq * 4;
     const unsigned out_off = (unsigned)((((qy * 8 + 2 * wty) * W + qx * 8 + 2 * wtx) * COUT + co4) * 4);
-    if (tid < 16) {      // the group's per-channel epilogue constants: read from LDS in the epilogue (one per tile), not held in registers
-        sE[tid] = EPI == EPI_SYNTH ? p.nscale[g * 16 + tid] : 0.f;
-        sE[16 + tid] = EPI == EPI_SYNTH ? p.nbias[g * 16 + tid] : 0.f;
-        sE[32 + tid] = EPI == EPI_DEC ? p.bn_s[g * 16 + tid] : 0.f;
-        sE[48 + tid] = EPI == EPI_DEC ? p.bn_beta[g * 16 + tid] : 0.f;
+    if (tid < 16 * NT) {      // the groups' per-channel epilogue constants: read from LDS in the epilogue (one per tile), not held in registers
+        float* e = sE + (tid >> 4) * 64 + (tid & 15);
+        const int co = g * NT * 16 + tid;
+        e[0] = EPI == EPI_SYNTH ? p.nscale[co] : 0.f;
+        e[16] = EPI == EPI_SYNTH ? p.nbias[co] : 0.f;
+        e[32] = EPI == EPI_DEC ? p.bn_s[co] : 0.f;
+        e[48] = EPI == EPI_DEC ? p.bn_beta[co] : 0.f;
     }
     const unsigned nz_off = (unsigned)((((qy * 8 + 2 * wty) * W + qx * 8 + 2 * wtx)) * 4);
     f32x2 nz[2] = {{0.f, 0.f}, {0.f, 0.f}};
     const int s2 = stat_s2(H * W);
     const bool odd = (lane & 1) != 0;
-    unsigned long long dI1[4] = {0ull, 0ull, 0ull, 0ull}, dI2[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned long long dI1[NT][4], dI2[NT][4];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dI1[ct][c] = dI2[ct][c] = 0ull;
     auto flush_stats = [&](int n) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            unsigned long long I1 = dI1[c], I2 = dI2[c];
+        for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1) { I1 += shfl_xor_u64(I1, m); I2 += shfl_xor_u64(I2, m); }
-            if (i16 == 0) {
-                StatPart* a = p.partials + ((size_t)n * p.prow + (blockIdx.x & (kDirectRows - 1))) * COUT + co4 + c;
-                atomicAdd(&a->s1, I1);
-                atomicAdd(&a->s2, I2);
+            for (int c = 0; c < 4; ++c) {
+                unsigned long long I1 = dI1[ct][c], I2 = dI2[ct][c];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { I1 += shfl_xor_u64(I1, m); I2 += shfl_xor_u64(I2, m); }
+                if (i16 == 0) {
+                    StatPart* a = p.partials + ((size_t)n * p.prow + (blockIdx.x & (kDirectRows - 1))) * COUT + co4 + ct * 16 + c;
+                    atomicAdd(&a->s1, I1);
+                    atomicAdd(&a->s2, I2);
+                }
+                dI1[ct][c] = dI2[ct][c] = 0ull;
             }
-            dI1[c] = dI2[c] = 0ull;
-        }
     };
     const f32x2 k02 = {0.2f, 0.2f};
     auto epilogue_loads = [&](const Tile& t) {
@@ -580,11 +607,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
         }
     };
 
-    f32x4 acc[16];
-    auto multiply = [&](auto first_tag, int buf) {
+    f32x4 accs[NT][16];
+    auto multiply = [&](auto first_tag, int buf, auto&& vm0, auto&& vm1) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const float* a_img = sA + buf * IMG + pbase;
-        const float* b_img = sB + buf * SEG + bbase;
+        const float* b_img = sB + buf * NT * SEG + bbase;
         f32x4 V[16];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -606,23 +633,59 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
             V[i * 4 + 3] = sub4(t1, t3);
             valu_settle(V[i * 4 + 0], V[i * 4 + 1], V[i * 4 + 2], V[i * 4 + 3]);
         }
+        if constexpr (IL == 1) {
+            f32x4 u[2][NT][4];
+            auto read_row = [&](int fb) {
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[fb & 1][ct][j] = *reinterpret_cast<const f32x4*>(b_img + ct * SEG + (fb * 4 + j) * 256);
+            };
+            read_row(0);
+            __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) {
+                if (fb < 3) read_row(fb + 1);
+                if (fb == 0) vm0();
+                if (fb == 2) vm1();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct) {
+                            const int f = fb * 4 + j;
+                            accs[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[fb & 1][ct][j][cg], V[f][cg], FIRST && cg == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : accs[ct][f], 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            return;
+        }
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
-            f32x4 u[4];
+            f32x4 u[NT][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) u[j] = *reinterpret_cast<const f32x4*>(b_img + (fb * 4 + j) * 256);
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[ct][j] = *reinterpret_cast<const f32x4*>(b_img + ct * SEG + (fb * 4 + j) * 256);
 #pragma unroll
             for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int f = fb * 4 + j;
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][cg], V[f][cg], FIRST && cg == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[f], 0, 0, 0);
-                }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct) {
+                        const int f = fb * 4 + j;
+                        accs[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[ct][j][cg], V[f][cg], FIRST && cg == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : accs[ct][f], 0, 0, 0);
+                    }
         }
         __builtin_amdgcn_s_setprio(0);
     };
-    auto epilogue = [&](const Tile& t) {
+    auto epilogue_ct = [&](const Tile& t, auto ct_tag) {
+        constexpr int ct = decltype(ct_tag)::value;
+        f32x4 (&acc)[16] = accs[ct];
         mfma_settle(acc);
         f32x4 s0[4], s1[4];
 #pragma unroll
@@ -633,9 +696,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
         f32x4 y[2][2];
         y[0][0] = add4(add4(s0[0], s0[1]), s0[2]); y[0][1] = sub4(sub4(s0[1], s0[2]), s0[3]);
         y[1][0] = add4(add4(s1[0], s1[1]), s1[2]); y[1][1] = sub4(sub4(s1[1], s1[2]), s1[3]);
-        char* ob = reinterpret_cast<char*>(p.out) + ((long)(t.n * H + t.y0) * W + t.x0) * COUT * 4;
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(sE + kq * 4), e1 = *reinterpret_cast<const f32x4*>(sE + 16 + kq * 4);
-        const f32x4 e2 = *reinterpret_cast<const f32x4*>(sE + 32 + kq * 4), e3 = *reinterpret_cast<const f32x4*>(sE + 48 + kq * 4);
+        char* ob = reinterpret_cast<char*>(p.out) + (((long)(t.n * H + t.y0) * W + t.x0) * COUT + ct * 16) * 4;
+        const float* sEc = sE + ct * 64 + kq * 4;
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(sEc), e1 = *reinterpret_cast<const f32x4*>(sEc + 16);
+        const f32x4 e2 = *reinterpret_cast<const f32x4*>(sEc + 32), e3 = *reinterpret_cast<const f32x4*>(sEc + 48);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -663,10 +727,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
             for (int c = 0; c < 4; ++c) {
                 const float keep_s = odd ? ps[1][c] : ps[0][c], send_s = odd ? ps[0][c] : ps[1][c];
                 const float keep_q = odd ? pq[1][c] : pq[0][c], send_q = odd ? pq[0][c] : pq[1][c];
-                dI1[c] += to_fixed(keep_s + dpp_quad<0xB1>(send_s), kStatScale1);
-                dI2[c] += to_fixed_sq(keep_q + dpp_quad<0xB1>(send_q), s2);
+                dI1[ct][c] += to_fixed(keep_s + dpp_quad<0xB1>(send_s), kStatScale1);
+                dI2[ct][c] += to_fixed_sq(keep_q + dpp_quad<0xB1>(send_q), s2);
             }
         }
+    };
+    auto epilogue = [&](const Tile& t) {
+        epilogue_ct(t, std::integral_constant<int, 0>{});
+        if constexpr (NT == 2) epilogue_ct(t, std::integral_constant<int, 1>{});
     };
 
     Tile tc, tr;
@@ -696,16 +764,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_stream(ConvParams p) {
         const bool has_next = it + 1 < items;
         TICK(k0);
         if (has_next) {
-            dma_weights(cbr, (it + 1) & 1);      // the panel buffer item it - 1 used: every wave is past that item's closing barrier
+            if (!IL) dma_weights(cbr, (it + 1) & 1);      // the panel buffer item it - 1 used: every wave is past that item's closing barrier
             write_item(tr, er, cbr, (it + 1) & 1);
         }
         TICK(k1);
         if (cbc == nblk - 1) epilogue_loads(tc);
         Tile t2 = tr; int e2c = er, cb2 = cbr;
-        if (it + 2 < items) { next_item(t2, e2c, cb2); load_item(t2, e2c, cb2); }
+        if (it + 2 < items) { next_item(t2, e2c, cb2); if (!IL) load_item(t2, e2c, cb2); }
         TICK(k2);
-        if (cbc == 0) multiply(std::true_type{}, it & 1);
-        else multiply(std::false_type{}, it & 1);
+        auto vm0 = [&]() { if (IL == 1 && has_next) dma_weights(cbr, (it + 1) & 1); };      // same order as the phased form: the DMA pieces are the older operations
+        auto vm1 = [&]() { if (IL == 1 && it + 2 < items) load_item(t2, e2c, cb2); };
+        if (cbc == 0) multiply(std::true_type{}, it & 1, vm0, vm1);
+        else multiply(std::false_type{}, it & 1, vm0, vm1);
         TICK(k3);
         if (cbc == nblk - 1) {
             epilogue(tc);
@@ -809,12 +879,12 @@ hipError_t launch_shape(const ConvParams& p, int epi, int n, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-template <int EPI, bool AFF>
+template <int EPI, bool AFF, int NT = 1, int IL = 0>
 hipError_t launch_stream_t(const ConvParams& p, int n, hipStream_t s) {
     static LeanState st[kMaxDev];
-    auto kern = conv3x3_wino_stream<EPI, AFF>;
+    auto kern = conv3x3_wino_stream<EPI, AFF, NT, IL>;
     const int nblk = p.C0 / 16;
-    const size_t lds = sizeof(float) * (2 * IMG + 2 * SEG + 64 + nblk * 32);
+    const size_t lds = sizeof(float) * (2 * IMG + 2 * NT * SEG + 64 * NT + nblk * 32);
     if (p.device < 0 || p.device >= kMaxDev) return hipErrorInvalidDevice;
     int cus;
     {
@@ -832,16 +902,16 @@ hipError_t launch_stream_t(const ConvParams& p, int n, hipStream_t s) {
     q.wpk = p.wino;
     q.tiles_x = p.W / 16;
     q.tiles_y = p.H / 16;
-    q.groups = p.Cout / 16;
+    q.groups = p.Cout / (16 * NT);                     // workgroup columns: a group (NT = 2: a pair of groups) each
     q.total_tiles = q.tiles_x * q.tiles_y * n;         // per output-channel group
     if (EPI == EPI_SYNTH) {
         q.stats_direct = 1;
         q.prow = kDirectRows;
         if (p.stat_rows_host) *p.stat_rows_host = q.prow;
     }
-    // persistent workgroups, two per CU, each inside its channel group; workgroup (x, g) has the linear index x + g * gx: with gx a
+    // persistent workgroups, two per CU (NT = 2: one), each inside its channel group; workgroup (x, g) has the linear index x + g * gx: with gx a
     // multiple of 8 the groups of a tile range meet in one XCD's L2 (conv3x3_wino's launch shape)
-    const int slots = std::max(1, cus * 2 / q.groups);
+    const int slots = std::max(1, cus * (NT == 1 ? 2 : 1) / q.groups);
     const int gx = std::min(q.total_tiles, slots);
     hipLaunchKernelGGL(kern, dim3(gx, q.groups), dim3(256), lds, s, q);
     return hipGetLastError();
@@ -872,10 +942,40 @@ bool wino_lean_fuses_torgb(const ConvParams& p, int epi, int nc) {
            wino_lean_applies(p, epi) && !single_buffered();
 }
 
-const char* wino_lean_name(const ConvParams& p, int epi) {
+// GSA_WINO_NT2=1 (experiments build; 2: on every streamed layer): two output groups per workgroup in the streamed-weight kernel -- one wave per
+// SIMD, 128 MFMAs per staged item -- where the layer still gives every CU a workgroup.  Same bits; measured EQUAL per layer (g.32 ... g.256.conv_2
+// 0.224/0.221/0.218/0.228 -> 0.227/0.220/0.218/0.232 ms), with the memory instructions inside the MFMA stream (GSA_WINO_IL=1) -4 % on three of them.
+bool stream_pairs(const ConvParams& p, int n) {
+#if GSA_EXPERIMENTS
+    static const int on = getenv("GSA_WINO_NT2") ? atoi(getenv("GSA_WINO_NT2")) : 0;
+    if (!on || p.Cout % 32) return false;
+    const long wgs = (long)(p.W / 16) * (p.H / 16) * n * (p.Cout / 32);
+    return wgs >= (on == 2 ? 1 : 256);
+#else
+    (void)p; (void)n;
+    return false;
+#endif
+}
+
+// GSA_WINO_IL=1 (experiments build): the paired streamed-weight kernel issues its memory instructions inside the MFMA stream -- speed only, same bits
+int stream_interleaved() {
+#if GSA_EXPERIMENTS
+    static const int il = getenv("GSA_WINO_IL") ? atoi(getenv("GSA_WINO_IL")) : 0;
+    return il == 1 ? 1 : 0;
+#else
+    return 0;
+#endif
+}
+
+const char* wino_lean_name(const ConvParams& p, int epi, int n) {
     static thread_local char buf[112];
     if (p.C0 >= 64) {
-        snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_stream<%d, %s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false");
+        const bool pairs = stream_pairs(p, n);
+        const int il = pairs ? stream_interleaved() : 0;
+        char tail[16] = "";
+        if (il) snprintf(tail, sizeof tail, ", 2, %d", il);
+        else if (pairs) snprintf(tail, sizeof tail, ", 2");
+        snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_stream<%d, %s%s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false", tail);
         return buf;
     }
     const bool sb = p.C0 == 16 && epi == EPI_DEC && single_buffered();
@@ -887,6 +987,20 @@ const char* wino_lean_name(const ConvParams& p, int epi) {
 
 hipError_t launch_wino_lean(const ConvParams& p, int epi, int n, hipStream_t s) {
     if (p.C0 >= 64) {
+#if GSA_EXPERIMENTS
+        if (stream_pairs(p, n)) {
+            const int il = stream_interleaved();
+#define GSA_STREAM2(IL_) \
+            if (il == IL_) { \
+                if (epi == EPI_SYNTH) return p.aff0 ? launch_stream_t<EPI_SYNTH, true, 2, IL_>(p, n, s) : launch_stream_t<EPI_SYNTH, false, 2, IL_>(p, n, s); \
+                if (epi == EPI_DEC) return p.aff0 ? launch_stream_t<EPI_DEC, true, 2, IL_>(p, n, s) : launch_stream_t<EPI_DEC, false, 2, IL_>(p, n, s); \
+                return hipErrorInvalidValue; \
+            }
+            GSA_STREAM2(0) GSA_STREAM2(1)
+#undef GSA_STREAM2
+            return hipErrorInvalidValue;
+        }
+#endif
         if (epi == EPI_SYNTH) return p.aff0 ? launch_stream_t<EPI_SYNTH, true>(p, n, s) : launch_stream_t<EPI_SYNTH, false>(p, n, s);
         if (epi == EPI_DEC) return p.aff0 ? launch_stream_t<EPI_DEC, true>(p, n, s) : launch_stream_t<EPI_DEC, false>(p, n, s);
         return hipErrorInvalidValue;

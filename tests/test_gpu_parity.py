@@ -904,7 +904,8 @@ _EXP = {"GSA_HIP_LIBRARY": "libgsa_hip_exp.so"}                               # 
     dict(_OLD, GSA_WRES="0", GSA_SUBRES="0", GSA_STATS_DIRECT="0"), dict(_OLD, GSA_WINO_GW="1"), dict(_OLD, GSA_WINO_GW="2"), dict(_OLD, GSA_WINO_PERS="32"),
     dict(_OLD, GSA_POST_NG="4"), dict(_OLD, GSA_SUBWST="0"), {"GSA_SUBWST": "0"}, {"GSA_FUSEFIN": "0"},
     # round 4's measured-slower kernels: in the experiments build only (conv3x3_wino_dma: every operand by LDS-DMA; two tiles per 8-wave workgroup)
-    dict(_EXP, GSA_WINO_DMA="1"), dict(_EXP, GSA_WINO_TW="2"), dict(_EXP, GSA_SUB_CNT="1")])
+    dict(_EXP, GSA_WINO_DMA="1"), dict(_EXP, GSA_WINO_TW="2"), dict(_EXP, GSA_SUB_CNT="1"),
+    dict(_EXP, GSA_WINO_NT2="2"), dict(_EXP, GSA_WINO_NT2="1", GSA_WINO_IL="1")])
 def test_speed_switches_do_not_change_the_bits(torch_cuda, tmp_path, env):
     """The A/B switches of DESIGN.md section 4 that are NOT part of the canonical arithmetic (channel tile of the Winograd
     kernel, group order, rows per thread of the post kernel, stream overlap, resident weights / persistent forms / direct
