@@ -406,6 +406,18 @@ size_t sub_lds(const ConvParams& q, int nt, bool sc, bool aff, int kb, bool wst,
                             (aff ? (cnt ? 8 : 2) * 2 * nblk0 * 32 : 0)) + (cnt ? 64 : 0);
 }
 
+// GSA_SUB_CNT=1 (experiments build): per-half progress words with a ring of three images instead of the eight-wave barrier (resident
+// panel; same bits).  Measured 2.3 % slower over the whole step (1290 against 1320 pairs/s on one box): see DESIGN.md section 5.
+bool sub_counters(const ConvParams& q, int nt, bool sc, int kb, bool wst) {
+#if GSA_EXPERIMENTS
+    static const bool cnt_on = getenv("GSA_SUB_CNT") && atoi(getenv("GSA_SUB_CNT")) != 0;
+    return cnt_on && !wst && sub_lds(q, nt, sc, q.aff0 != nullptr, kb, false, true) <= 160 * 1024;
+#else
+    (void)q; (void)nt; (void)sc; (void)kb; (void)wst;
+    return false;
+#endif
+}
+
 template <int NT, int EPI, bool SC, bool AFF, int KB, bool WST, bool CNT = false>
 hipError_t launch_k(const ConvParams& q, dim3 grid, hipStream_t s) {
     static SubState st[kMaxDev];
@@ -428,10 +440,7 @@ template <int NT, int EPI, bool SC, bool AFF>
 hipError_t launch_shape(const ConvParams& q, int kb, bool wst, dim3 grid, hipStream_t s) {
     if (wst) return launch_k<NT, EPI, SC, AFF, 1, true>(q, grid, s);
 #if GSA_EXPERIMENTS
-    // GSA_SUB_CNT=1 (experiments build): per-half progress words with a ring of three images instead of the eight-wave barrier (resident
-    // panel; same bits).  Measured 2.3 % slower over the whole step (1290 against 1320 pairs/s on one box): see DESIGN.md section 5.
-    static const bool cnt_on = getenv("GSA_SUB_CNT") && atoi(getenv("GSA_SUB_CNT")) != 0;
-    if (cnt_on && sub_lds(q, NT, SC, AFF, kb, false, true) <= 160 * 1024)
+    if (sub_counters(q, NT, SC, kb, false))
         return kb == 2 ? launch_k<NT, EPI, SC, AFF, 2, false, true>(q, grid, s) : launch_k<NT, EPI, SC, AFF, 1, false, true>(q, grid, s);
 #endif
     return kb == 2 ? launch_k<NT, EPI, SC, AFF, 2, false>(q, grid, s) : launch_k<NT, EPI, SC, AFF, 1, false>(q, grid, s);
@@ -450,8 +459,8 @@ bool subpixel_lean_applies(const ConvParams& p, int nt, int epi, bool sc, int kb
 
 const char* subpixel_lean_name(const ConvParams& p, int nt, int epi, bool sc, int kb, bool wst) {
     static thread_local char buf[112];
-    snprintf(buf, sizeof buf, "void gsa::lean::subpixel_lean<%d, %d, %s, %s, %d, %s>(gsa::ConvParams)", nt, epi, sc ? "true" : "false",
-             p.aff0 ? "true" : "false", kb, wst ? "true" : "false");
+    snprintf(buf, sizeof buf, "void gsa::lean::subpixel_lean<%d, %d, %s, %s, %d, %s, %s>(gsa::ConvParams)", nt, epi, sc ? "true" : "false",
+             p.aff0 ? "true" : "false", kb, wst ? "true" : "false", lean::sub_counters(p, nt, sc, kb, wst) ? "true" : "false");
     return buf;
 }
 

@@ -972,10 +972,7 @@ const char* wino_lean_name(const ConvParams& p, int epi, int n) {
     if (p.C0 >= 64) {
         const bool pairs = stream_pairs(p, n);
         const int il = pairs ? stream_interleaved() : 0;
-        char tail[16] = "";
-        if (il) snprintf(tail, sizeof tail, ", 2, %d", il);
-        else if (pairs) snprintf(tail, sizeof tail, ", 2");
-        snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_stream<%d, %s%s>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false", tail);
+        snprintf(buf, sizeof buf, "void gsa::lean::conv3x3_wino_stream<%d, %s, %d, %d>(gsa::ConvParams)", epi, p.aff0 ? "true" : "false", pairs ? 2 : 1, il);
         return buf;
     }
     const bool sb = p.C0 == 16 && epi == EPI_DEC && single_buffered();
