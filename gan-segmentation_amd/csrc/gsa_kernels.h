@@ -106,6 +106,10 @@ bool subpixel_uses_wino(const ConvParams& p);                      // true: Wino
 hipError_t launch_post(const PostParams& p, int n, hipStream_t s);
 // gsa_post_lean.hip (round 5): post_rows_kernel<4> in packed fp32 arithmetic (same bits).  GSA_POST_PK: 0 = off, 1 = packed (default), 2 = + non-temporal stores
 int post_pk_mode();
+bool post_dma_applies(const PostParams& p);      // GSA_POST_DMA: the LDS-DMA ring form (16 / 32 channels, fp32, blurred)
+int post_dma_band(const PostParams& p);
+int post_dma_blocks(const PostParams& p);
+hipError_t launch_post_dma(const PostParams& p, int n, hipStream_t s);
 hipError_t launch_post_pk(const PostParams& q, dim3 grid, size_t lds, hipStream_t s);
 hipError_t launch_finalize(const FinalizeParams& p, int n, hipStream_t s);
 bool conv_fuses_finalize(const ConvParams& p, int epi, bool shortcut);   // true: launch_conv3x3 writes the layer's AdaIN coefficients itself when p.fin_aff is set (whole-plane K-split tiles)

@@ -4474,6 +4474,7 @@ static int post_row_groups(const PostParams& p) {
 }
 
 static int post_blocks(const PostParams& p) {
+    if (post_dma_applies(p)) return post_dma_blocks(p);
     const int rpt = post_rpt(p);
     return rpt == 1 ? post_prow(p.H, p.W, p.C) : ((p.H / (rpt * post_row_groups(p))) * (p.W / 4) * (p.C / 4) + 255) / 256;
 }
@@ -4489,6 +4490,7 @@ hipError_t launch_post(const PostParams& p, int n, hipStream_t s) {
     const int rpt = post_rpt(p);
     q.prow = post_rows_used(p);
     q.row_groups = post_row_groups(p);
+    if (post_dma_applies(p)) return launch_post_dma(q, n, s);
     dim3 grid(post_blocks(p), n);
     const size_t lds = sizeof(unsigned long long) * 2 * p.C;
     // the packed-arithmetic form (gsa_post_lean.hip): four rows per thread, a wave's 64 threads inside one row group

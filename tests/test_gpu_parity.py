@@ -890,14 +890,14 @@ print("SWITCH_OK")
 '''
 
 
-_OLD = {"GSA_WINO_LEAN": "0", "GSA_SUB_LEAN": "0", "GSA_POST_PK": "0"}      # the kernels of rounds 1-4 (the fallbacks): their own switches only act there
+_OLD = {"GSA_WINO_LEAN": "0", "GSA_SUB_LEAN": "0", "GSA_POST_PK": "0", "GSA_POST_DMA": "0"}      # the kernels of rounds 1-4 (the fallbacks): their own switches only act there
 _EXP = {"GSA_HIP_LIBRARY": "libgsa_hip_exp.so"}                               # `make experiments`: + the measured-slower kernels of round 4
 
 
 @pytest.mark.parametrize("env", [
     # round 5: the lean kernels off / partly on, the single-buffered three-workgroups-per-CU form, the packed post pass and final conv
     _OLD, {"GSA_WINO_LEAN": "1"}, {"GSA_WINO_LEAN": "3"}, {"GSA_SUB_LEAN": "0"}, {"GSA_POST_PK": "0"}, {"GSA_POST_PK": "2"}, {"GSA_FINAL_PK": "0"},
-    {"GSA_WINO_LEAN_SB": "1"}, {"GSA_WINO_LEAN_PF": "2"}, {"GSA_FUSE_RGB": "0"},
+    {"GSA_WINO_LEAN_SB": "1"}, {"GSA_WINO_LEAN_PF": "2"}, {"GSA_FUSE_RGB": "0"}, {"GSA_POST_DMA": "0"}, {"GSA_POST_DMA_OST": "0"}, {"GSA_POST_DMA_BH": "16"},
     # rounds 2-4, on the fallback kernels they belong to
     dict(_OLD, GSA_WINO_NT="2"), dict(_OLD, GSA_WINO_GM="0"), dict(_OLD, GSA_WINO_CHUNK="1"), dict(_OLD, GSA_WINO_CHUNK="0"), dict(_OLD, GSA_POST_RPT="1"),
     dict(_OLD, GSA_POST_RPT="8"), {"GSA_SIDE_LEVELS": "0"}, {"GSA_MAPFUSE": "0"}, {"GSA_KSPLIT_PS": "1"}, {"GSA_FEWROWS": "0"},
