@@ -213,6 +213,37 @@ def measure_end_to_end(gen, B, steps, dev):
     return out
 
 
+def measure_box(dev):
+    """Two figures that describe the BOX the line was measured on, not this repository (the pool's boxes differ by a few per cent for the
+    same build: `box` lets two lines be compared): what a 512 MiB device-to-device copy reaches (torch's copy kernel; read + written bytes)
+    and what an fp32 4096^3 GEMM of the vendor library reaches (the matrix pipe at whatever clock the box sustains)."""
+    import torch
+    n = 128 * 1024 * 1024
+    x = torch.ones(n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    a = torch.randn(4096, 4096, dtype=torch.float32, device=dev)
+    b = torch.randn(4096, 4096, dtype=torch.float32, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize(dev)
+        best = float("inf")
+        for _ in range(3):
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            best = min(best, e0.elapsed_time(e1) / reps)
+        return best
+
+    copy_ms = timed(lambda: y.copy_(x), 10)
+    gemm_ms = timed(lambda: torch.mm(a, b), 5)
+    return {"copy_512MiB_tb_per_s": round(2 * n * 4 / copy_ms / 1e9, 2), "sgemm_4096_tflops": round(2 * 4096.0 ** 3 / gemm_ms / 1e9, 1),
+            "note": "box calibration (torch copy kernel / vendor fp32 GEMM), independent of this repository's kernels"}
+
+
 def measure_generate_job(gan, n, batch, dev):
     """BASELINE.json configs[2]'s workload on ONE card, as the reference runs it (main.py:75-104): `main.py generate` end to end --
     .params files loaded from disk, `n` samples in batches of `batch` (the 8-GPU node's global batch of 32 on a single GPU),
@@ -673,6 +704,10 @@ def main():
             if (args.gan, args.precision, B) != ("cars", "bf16", 4):
                 sec.append(measure_secondary("cars", 4, "bf16", 40, 6, dev, graph=True))   # per-GPU share of configs[4], the replayed step
             out["secondary"] = sec
+            try:
+                out["box"] = measure_box(dev)
+            except Exception as e:      # calibration only: never costs the line
+                out["box"] = {"error": "%s: %s" % (type(e).__name__, e)}
             wall["secondary"] = round(time.perf_counter() - t1, 2)
         if world == 1 and not args.no_cpu_baseline:
             t1 = time.perf_counter()
