@@ -97,6 +97,10 @@ const char* wino_lean_name(const ConvParams& p, int epi, int n);
 hipError_t launch_wino_lean(const ConvParams& p, int epi, int n, hipStream_t s);
 bool wino_lean_fuses_torgb(const ConvParams& p, int epi, int nc);      // the lean kernel's own conditions
 bool conv_fuses_torgb(const ConvParams& p, int epi, bool shortcut, int nc);      // true: launch_conv3x3 on p (rgb_* set) also produces toRGB's uint8 image
+// gsa_bf16_lean.hip (round 5): the bf16 mode's 3x3 convolutions from 32 px on in the lean form (GSA_BF16_LEAN=0: conv3x3_mfma<..., true>)
+bool bf16_lean_applies(const ConvParams& p, int epi, bool shortcut);
+const char* bf16_lean_name(const ConvParams& p, int epi, int n);
+hipError_t launch_bf16_lean(const ConvParams& p, int epi, int n, hipStream_t s);
 // gsa_sub_lean.hip (round 5): subpixel_res<..., WINO> (fp32) in a leaner instruction stream -- speed only, same bits (GSA_SUB_LEAN=0: subpixel_res)
 bool subpixel_lean_applies(const ConvParams& p, int nt, int epi, bool sc, int kb, bool wst);
 const char* subpixel_lean_name(const ConvParams& p, int nt, int epi, bool sc, int kb, bool wst);

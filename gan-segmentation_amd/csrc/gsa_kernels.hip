@@ -4208,6 +4208,7 @@ const char* conv3x3_kernel_name(const ConvParams& p, int epi, bool sc, int n) {
         snprintf(buf, sizeof buf, "void gsa::conv3x3_ksplit<%d, %d, %s, %d>(gsa::ConvParams)", p.H == 4 ? 4 : 8, epi, p.bf16 ? "true" : "false", p.H == 4 ? 1 : ksplit_ps());
         return buf;
     }
+    if (bf16_lean_applies(p, epi, sc)) return bf16_lean_name(p, epi, n);
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
     snprintf(buf, sizeof buf, "void gsa::conv3x3_mfma<%d, %d, %d, %d, %d, %d, %s, %s>(gsa::ConvParams)", c.th, c.th, c.wm, c.wn, c.nt,
              epi, sc ? "true" : "false", p.bf16 ? "true" : "false");
@@ -4221,6 +4222,7 @@ hipError_t launch_conv3x3(const ConvParams& p, int epi, bool sc, int n, hipStrea
 #endif
     if (conv_uses_wino(p, epi, sc)) return launch_wino(p, epi, n, s);
     if (conv_uses_ksplit(p, sc)) return launch_ksplit(p, epi, n, s);
+    if (bf16_lean_applies(p, epi, sc)) return launch_bf16_lean(p, epi, n, s);
     const ConvGeom c = pick_geom(p.H, p.W, p.Cout, n);
 #define GSA_GEOM(TH, WM, WN, NT) \
     if (c.th == TH && c.wm == WM && c.wn == WN && c.nt == NT) return launch_conv_e<TH, TH, WM, WN, NT>(p, epi, sc, n, s);

@@ -115,3 +115,40 @@ def test_config5_cars_512_bf16(torch_cuda, oracle_lib):
     o32 = oracle_lib.Oracle(gcfg, gp, dcfg, dp)
     img_o32, mask_o32 = o32.generate(z[3:], [a[3:] for a in noise])
     assert np.array_equal(img32[3:], img_o32) and np.array_equal(mask32[3:], mask_o32)
+
+
+_BF16_LEAN_WORKER = r'''
+import hashlib, sys
+sys.path.insert(0, ROOT_DIR)
+import numpy as np
+from tests.common import gan_setup, reduced_setup
+from gan_segmentation_amd.image_generator import ImageGenerator
+for name, setup, batch in (("reduced", reduced_setup(7, batch=3, trivial_norm=False), 3), ("cars", gan_setup("cars", 2), 2)):
+    gcfg, gp, dcfg, dp, z, noise = setup
+    gen = ImageGenerator.from_params(gcfg, gp, dcfg, dp, gpu_ids=[0], batch_size=batch, precision="bf16")
+    rgb, feats, img = gen.netG(z, noise=noise, want_image=True)
+    logits, mask = gen._decoder(*feats, want_mask=True)
+    h = hashlib.sha256()
+    for t in [rgb, img, logits, mask] + list(feats):
+        h.update(np.ascontiguousarray(t.cpu().numpy()).tobytes())
+    print("DIGEST", name, h.hexdigest())
+'''
+
+
+def test_bf16_lean_kernels_give_the_general_kernels_values(torch_cuda, tmp_path):
+    """conv3x3_bf16_lean (round 5) replaces conv3x3_mfma<..., BF = true> from 32 px on: the same products in the same chain order with the same
+    roundings -- not a tolerance: every tensor of the bf16 mode (rgb, image, logits, mask, all features) has the same bytes with GSA_BF16_LEAN=0
+    and =1, on the reduced 128-px model (odd batch, loaded norm parameters) and on cars 512^2.  (Child processes: the switch is read once.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "bf16_lean_worker.py"
+    script.write_text(_BF16_LEAN_WORKER.replace("ROOT_DIR", repr(root)))
+    digests = {}
+    for v in ("0", "1"):
+        out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, GSA_BF16_LEAN=v, GSA_GRAPH="0"), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-800:] + out.stderr[-2500:]
+        digests[v] = sorted(l for l in out.stdout.splitlines() if l.startswith("DIGEST"))
+        assert len(digests[v]) == 2, out.stdout[-800:]
+    assert digests["0"] == digests["1"], digests
