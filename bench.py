@@ -487,6 +487,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50, help="timed steps (default 50: a third of a second of GPU time at FFHQ batch 8)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-steps", type=int, default=80,
+                    help="untimed steps in front of the warm-up (default 80 = half a second at FFHQ batch 8): an idle MI355X needs a few tenths of a "
+                         "second of load before its clocks settle -- without them the first one or two timed regions read 3 %% low (the same count on every rank)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions of --steps steps each, back to back after ONE warm-up; value = their median, every region is printed (runs)")
     ap.add_argument("--gan", default="ffhq", choices=("ffhq", "cars", "bedrooms"))
@@ -548,7 +551,7 @@ def main():
         gat = gdist.PairGatherer(B, R, nch, device=dev, dst=0, depth=2)
         producer = StubProducer(rank, B, R, nch)
         loop = TimedLoop(producer, gat, world, dev, args.allow_blocking)
-        timing = loop.run(args.warmup, args.steps, args.repeats)
+        timing = loop.run(args.settle_steps + args.warmup, args.steps, args.repeats)
         dt = median([loop.max_over_ranks(d) for d in timing["dts_local"]])
         if rank == 0:
             # content and order of the last gathered batch: rank r's row must hold rank r's pairs of the last step
@@ -556,7 +559,7 @@ def main():
             if timing["gather"] != "blocking":
                 parts = gat.result(timing["last_slot"])
                 for r in range(ranks):
-                    wi, wm = StubProducer(r, B, R, nch).pairs(args.warmup + args.steps * max(1, args.repeats) - 1)
+                    wi, wm = StubProducer(r, B, R, nch).pairs(args.settle_steps + args.warmup + args.steps * max(1, args.repeats) - 1)
                     ok = ok and bool(torch.equal(parts[r][0], wi)) and bool(torch.equal(parts[r][1], wm))
             print(json.dumps({
                 "metric": "bench.py control-flow rehearsal (stub producer, NOT a measurement)",
@@ -598,7 +601,7 @@ def main():
     t_setup = time.perf_counter() - t_proc
     # ---- timed region: EXACTLY K steps (no per-launch events here: 2 event packets around each of the
     # ~130 launches of a step cost ~5 % of the step)
-    timing = loop.run(args.warmup, args.steps, args.repeats)
+    timing = loop.run(args.settle_steps + args.warmup, args.steps, args.repeats)
     t_warm, state, last_slot = timing["warmup_s"], {"gather": timing["gather"]}, timing["last_slot"]
     # ---- roofline pass (untimed): the same K steps with every launch bracketed by HIP events on its
     # stream, and with the decoder/synthesis stream overlap off, so that a kernel's duration is its own
@@ -636,7 +639,7 @@ def main():
             "metric": "synthetic (image,mask) pairs/sec, %s-%d StyleGAN+decoder" % (args.gan.upper(), 2 ** mr),
             "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "ranks": ranks, "devices": devices, "launcher": launcher,
             "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
+            "warmup": args.warmup, "settle_steps": args.settle_steps, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
             # the spread of the headline: `repeats` regions of exactly `steps` steps each, back to back after one warm-up; value and
             # ms_per_step are the MEDIAN region's, runs[] holds every region in the order it was timed
             "repeats": len(dts), "runs": [round(world * B * args.steps / d, 3) for d in dts],
