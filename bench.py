@@ -709,6 +709,10 @@ def main():
             out["secondary"] = sec
             try:
                 out["box"] = measure_box(dev)
+                if args.precision == "fp32" and out["roofline"].get("bound") == "mfma" and out["box"].get("sgemm_4096_tflops"):
+                    # the dominant kernel's executed rate against what the vendor's own fp32 GEMM reaches on this box (context for `frac`,
+                    # which stays priced against the nominal peak)
+                    out["box"]["dominant_kernel_over_sgemm"] = round(out["roofline"]["executed_tflops"] / out["box"]["sgemm_4096_tflops"], 4)
             except Exception as e:      # calibration only: never costs the line
                 out["box"] = {"error": "%s: %s" % (type(e).__name__, e)}
             wall["secondary"] = round(time.perf_counter() - t1, 2)
