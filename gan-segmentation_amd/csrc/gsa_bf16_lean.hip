@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256, (EPI == EPI_SYNTH || NT == 4 || (RES && NT == 
         w_src[j] = (unsigned)(((c / 288) * nblk * BSEG + (c % 288) * 4) * 4);
     }
     auto dma_weights = [&](int cb, int buf) {
+#ifdef GSA_DBG_HOOKS
+        if (p.dbg & 1024) return;     // diagnostic build only (WRONG results): no weight DMA
+#endif
         const char* wb = reinterpret_cast<const char*>(wgrp + (size_t)cb * BSEG);
 #pragma unroll
         for (int j = 0; j < WR; ++j)
@@ -96,6 +99,9 @@ __global__ __launch_bounds__(256, (EPI == EPI_SYNTH || NT == 4 || (RES && NT == 
     };
     auto load_item = [&](auto set_tag, const BTile& t, int e, int cb) {
         constexpr int S = decltype(set_tag)::value;
+#ifdef GSA_DBG_HOOKS
+        if (p.dbg & 512) return;      // diagnostic build only (WRONG results): no activation loads
+#endif
         const char* hb = reinterpret_cast<const char*>(p.src0) + ((((long)(t.n * H + t.y0) * W + t.x0) - (W + 1)) * CIN + cb * 16) * 2;
         if (e) {
 #pragma unroll
@@ -121,6 +127,9 @@ __global__ __launch_bounds__(256, (EPI == EPI_SYNTH || NT == 4 || (RES && NT == 
     };
     auto write_item = [&](auto set_tag, const BTile& t, int e, int cb, int buf) {
         constexpr int S = decltype(set_tag)::value;
+#ifdef GSA_DBG_HOOKS
+        if (p.dbg & 128) return;      // diagnostic build only (WRONG results): no staging (AdaIN + LDS stores)
+#endif
         float* img = sA + buf * BIMG;
         if (AFF && t.n != n_coef) { coefficients(t.n); n_coef = t.n; }
         f32x4 kA0 = {0.f, 0.f, 0.f, 0.f}, kA1 = kA0, kB0 = kA0, kB1 = kA0;
@@ -214,6 +223,9 @@ __global__ __launch_bounds__(256, (EPI == EPI_SYNTH || NT == 4 || (RES && NT == 
     f32x4 acc[NT][4];
     auto multiply = [&](auto first_tag, int buf, int wslot) {
         constexpr bool FIRST = decltype(first_tag)::value;
+#ifdef GSA_DBG_HOOKS
+        if (p.dbg & 256) { if (FIRST) for (int q = 0; q < NT; ++q) for (int m = 0; m < 4; ++m) acc[q][m] = f32x4{0.f, 0.f, 0.f, 0.f}; return; }      // no operand reads, no MFMAs
+#endif
         const float* a_img = sA + buf * BIMG;
         const float* b_img = sB + wslot * NT * BSEG + bbase;
         __builtin_amdgcn_s_setprio(2);
@@ -252,6 +264,9 @@ __global__ __launch_bounds__(256, (EPI == EPI_SYNTH || NT == 4 || (RES && NT == 
                 const f32x2 tlo = pk_mul2(e0.xy, n2), thi = pk_mul2(e0.zw, n2);
                 v = lrelu4(add4(add4(v, f32x4{tlo.x, tlo.y, thi.x, thi.y}), e1), k02);
             }
+#ifdef GSA_DBG_HOOKS
+            if (!(p.dbg & 64))        // diagnostic build only (WRONG results): no output stores
+#endif
             *reinterpret_cast<u32x2*>(ob + out_off[m] + q * 32) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
             if (EPI == EPI_SYNTH) {
                 // statistics per aligned x-quad (the four lanes of a quad hold x .. x + 3 of one row): s = (v0 + v1) + (v2 + v3), q likewise
