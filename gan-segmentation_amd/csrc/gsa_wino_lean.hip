@@ -438,6 +438,28 @@ __global__ __launch_bounds__(256 * GW, GW == 1 ? (DB ? 2 : 3) : 1) void conv3x3_
     }
 }
 
+// ---- anti-phase start (experiment) ----------------------------------------------------------------------------------------------------------
+// Two workgroups share a CU; they start together, do the same work and therefore stay IN PHASE: both stage while the matrix pipe idles, both
+// multiply while it is shared (the stamps' MFMA column is twice the MFMAs' own time; the timing-only decomposition of tools/dbg_stream.sh shows
+// the phases adding up instead of overlapping).  Nothing re-phases them either -- an offset given once persists.  So every second workgroup
+// to arrive on a CU (a ticket from a per-CU counter, CU = XCC / SE / SH / CU of HW_ID) sleeps `cycles64` x 64 cycles before its first item.
+__device__ unsigned g_cu_tickets[4096];
+__device__ __forceinline__ void antiphase_start(int cycles64, float* lds_word) {
+    if (cycles64 <= 0) return;
+    if (threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned cu = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+        *reinterpret_cast<unsigned*>(lds_word) = atomicAdd(&g_cu_tickets[cu & 4095u], 1u);
+    }
+    __syncthreads();
+    const unsigned ticket = *reinterpret_cast<volatile unsigned*>(lds_word);
+    __syncthreads();
+    if (ticket & 1u)
+        for (int i = 0; i < cycles64; i += 16) __builtin_amdgcn_s_sleep(16);
+}
+
 // ---- the streamed-weight layers (>= 64 input channels: g.16 ... g.256.conv_2, d.cvt_4 ... 6 of the FFHQ path) in the same lean form ----------
 // One workgroup = 4 waves on 16x16 tiles x ONE 16-channel output group (blockIdx.y), an item = (tile, 16-channel block).  As conv3x3_wino<EPI, 1,
 // true, AFF, 1>: double-buffered image and weight block, activations prefetched two items ahead through registers, accumulators across the
@@ -475,6 +497,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino_stream(Conv
     const int w_end = min(p.total_tiles, w_begin + per);
     if (w_begin >= w_end) return;
     const int items = (w_end - w_begin) * nblk;
+#if GSA_EXPERIMENTS
+    antiphase_start(p.group_minor, sC);      // experiments build: group_minor carries GSA_STAGGER (64-cycle units; 0 = off)
+#endif
 
     unsigned s_off[NCH], eflags = 0;
     int l_off[NCH];
@@ -492,11 +517,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino_stream(Conv
     auto advance = [&](Tile& t) { t.x0 += 16; if (t.x0 == W) { t.x0 = 0; t.y0 += 16; if (t.y0 == H) { t.y0 = 0; t.n += 1; } } };
 
     f32x4 ra[NCH];                                // the item in flight: this thread's activation chunks
+    int dbg_items = 0; (void)dbg_items;           // diagnostic build: the first two items always run in full (valid data in both LDS buffers)
     const float* const wgrp = p.wpk + (size_t)g * NT * nblk * SEG + lane * 4;
     // the item's weight block(s): pieces wave, wave + 4, wave + 8, wave + 12 of 1 KB each per group, straight into the LDS panel
     auto dma_weights = [&](int cb, int buf) {
 #ifdef GSA_DBG_HOOKS
         if (p.dbg & 16) cb = 0;      // diagnostic build only (WRONG results): the weight stream stays in L2
+        if ((p.dbg & 1024) && dbg_items > 2) return;      // ... no weight DMA
 #endif
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
@@ -513,6 +540,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino_stream(Conv
         const char* hb = reinterpret_cast<const char*>(p.src0) + ((((long)(t.n * H + t.y0) * W + t.x0) - (W + 1)) * CIN + cb * 16) * 4;
 #ifdef GSA_DBG_HOOKS
         if (p.dbg & 32) hb = reinterpret_cast<const char*>(p.src0) + ((long)(W + 1) * CIN) * 4;      // diagnostic build only (WRONG results): one input tile, block 0
+        if ((p.dbg & 512) && dbg_items > 2) return;       // ... no activation loads (the registers keep an earlier item)
 #endif
         if (e) {
 #pragma unroll
@@ -539,6 +567,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino_stream(Conv
     auto write_item = [&](const Tile& t, int e, int cb, int buf) {
         float* img = sA + buf * IMG;
         if (AFF && t.n != n_coef) { coefficients(t.n); n_coef = t.n; }
+#ifdef GSA_DBG_HOOKS
+        if (++dbg_items > 2 && (p.dbg & 128)) return;      // diagnostic build only (WRONG results): no staging (AdaIN + LDS stores)
+#endif
         f32x4 kA = {0.f, 0.f, 0.f, 0.f}, kB = kA;
         if (AFF) {
             kA = *reinterpret_cast<const f32x4*>(sC + cb * 32 + part * 4);
@@ -610,6 +641,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino_stream(Conv
     f32x4 accs[NT][16];
     auto multiply = [&](auto first_tag, int buf, auto&& vm0, auto&& vm1) {
         constexpr bool FIRST = decltype(first_tag)::value;
+#ifdef GSA_DBG_HOOKS
+        if ((p.dbg & 256) && dbg_items > 2) {      // diagnostic build only (WRONG results): no patch reads, transform, weight reads, MFMAs
+            if (FIRST) for (int ct = 0; ct < NT; ++ct) for (int f = 0; f < 16; ++f) accs[ct][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+#endif
         const float* a_img = sA + buf * IMG + pbase;
         const float* b_img = sB + buf * NT * SEG + bbase;
         f32x4 V[16];
@@ -712,6 +749,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino_stream(Conv
                     v = lrelu4(add4(add4(v, f32x4{tlo.x, tlo.y, thi.x, thi.y}), e1), k02);
                     y[i][j] = v;
                 }
+#ifdef GSA_DBG_HOOKS
+                if (!(p.dbg & 64))        // diagnostic build only (WRONG results): no output stores
+#endif
                 *reinterpret_cast<f32x4*>(ob + ((long)i * W + j) * COUT * 4 + out_off) = v;
             }
         if (EPI == EPI_SYNTH) {      // statistics: see conv3x3_wino_lean
@@ -903,6 +943,12 @@ hipError_t launch_stream_t(const ConvParams& p, int n, hipStream_t s) {
     q.tiles_x = p.W / 16;
     q.tiles_y = p.H / 16;
     q.groups = p.Cout / (16 * NT);                     // workgroup columns: a group (NT = 2: a pair of groups) each
+#if GSA_EXPERIMENTS
+    static const int stagger = getenv("GSA_STAGGER") ? atoi(getenv("GSA_STAGGER")) : 0;
+    q.group_minor = stagger;
+#else
+    q.group_minor = 0;
+#endif
     q.total_tiles = q.tiles_x * q.tiles_y * n;         // per output-channel group
     if (EPI == EPI_SYNTH) {
         q.stats_direct = 1;
